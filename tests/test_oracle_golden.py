@@ -1,0 +1,140 @@
+"""Pins the CPU oracle (oracle/uresnet_oracle.py) to vectors recorded from the reference.
+
+The golden files were produced by tests/golden/make_golden.py, which runs the reference's
+own model files.  Same torch build => the restatement must reproduce them to float
+round-off (thread-count dependent reduction order is the only slack allowed: 2e-6)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from cases import MODULE_CASES, SEG_MODEL_CASES, OracleNS
+from conftest import load_golden, rel_l2, state_from
+
+TOL = 2e-6
+
+
+def _sha(t):
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", sorted(MODULE_CASES))
+def test_block_matches_reference(oracle, name):
+    flavour, build = MODULE_CASES[name]
+    rec = load_golden(name)
+    m = build(OracleNS(oracle, flavour))
+    m.load_state_dict(state_from(rec), strict=True)
+    m.train()
+    xs = []
+    i = 0
+    while "x%d" % i in rec:
+        xs.append(torch.from_numpy(rec["x%d" % i]).requires_grad_(True))
+        i += 1
+    out = m(*xs)
+    assert rel_l2(out, rec["out"]) < TOL
+    (out * torch.from_numpy(rec["gout"])).sum().backward()
+    for i, x in enumerate(xs):
+        assert rel_l2(x.grad, rec["dx%d" % i]) < 20 * TOL, "dx%d" % i
+    for k, p in m.named_parameters():
+        if "grad/" + k in rec:
+            g = torch.from_numpy(rec["grad/" + k])
+            assert (p.grad - g).abs().max().item() <= 1e-4 * max(1.0, g.abs().max().item()), k
+    sd = m.state_dict()
+    for k in rec:
+        if k.startswith("w1/"):
+            assert rel_l2(sd[k[3:]].double(), rec[k].astype(np.float64)) < TOL, k
+    if "out_eval" in rec:
+        m.eval()
+        with torch.no_grad():
+            assert rel_l2(m(*[x.detach() for x in xs]), rec["out_eval"]) < TOL
+
+
+def test_channel_shuffle_bit_exact(oracle):
+    rec = load_golden("channel_shuffle")
+    x = torch.from_numpy(rec["x"])
+    for g in (2, 4, 8, 16):
+        assert torch.equal(oracle.channel_shuffle(x, g), torch.from_numpy(rec["g%d" % g]))
+    assert torch.equal(oracle.channel_shuffle(x, 16), x)     # groups == C is the identity
+
+
+def test_losses_and_masks(oracle):
+    rec = load_golden("losses_masks")
+    lg = torch.from_numpy(rec["ce_logits"]).requires_grad_(True)
+    loss = oracle.compute_loss(lg, torch.from_numpy(rec["ce_target"]))
+    loss.backward()
+    assert abs(loss.item() - rec["ce_loss"].item()) < 1e-6
+    assert rel_l2(lg.grad, rec["ce_dlogits"]) < TOL
+    lc = torch.from_numpy(rec["cls_logits"]).requires_grad_(True)
+    loss = oracle.cls_loss(lc, torch.from_numpy(rec["cls_target"]))
+    loss.backward()
+    assert abs(loss.item() - rec["cls_loss"].item()) < 1e-6
+    assert rel_l2(lc.grad, rec["cls_dlogits"]) < TOL
+    lb = torch.from_numpy(rec["bce_logits"]).requires_grad_(True)
+    loss = oracle.bce_loss(lb, torch.from_numpy(rec["bce_target"]))
+    loss.backward()
+    assert abs(loss.item() - rec["bce_loss"].item()) < 1e-6
+    assert rel_l2(lb.grad, rec["bce_dlogits"]) < TOL
+    assert torch.equal(oracle.argmax_mask(torch.from_numpy(rec["am_logits"])), torch.from_numpy(rec["am_mask"]))
+    assert torch.equal(oracle.sigmoid_mask(torch.from_numpy(rec["sg_logits"])), torch.from_numpy(rec["sg_mask"]))
+
+
+@pytest.mark.parametrize("name", sorted(SEG_MODEL_CASES))
+def test_seg_model_matches_reference(oracle, name):
+    cls, args, classes = SEG_MODEL_CASES[name]
+    rec = load_golden(name)
+    torch.manual_seed(0)
+    m = getattr(oracle, cls)(*args)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(rec["keys"])            # state_dict layout is the checkpoint contract
+    assert [_sha(v) for v in sd.values()] == list(rec["w0_sha"])   # same seed + same construction order
+    m.train()
+    x = torch.from_numpy(rec["x"])
+    tgt = torch.from_numpy(rec["target"])
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    step = oracle.seg_train_step if classes > 1 else oracle.ice_train_step
+    losses = []
+    for s in range(len(rec["losses"])):
+        loss, out = step(m, opt, x, tgt)
+        losses.append(loss.item())
+        if s == 0:
+            assert rel_l2(out, rec["logits"]) < TOL
+            grads = dict((k, p.grad) for k, p in m.named_parameters() if p.grad is not None)
+            assert list(grads.keys()) == list(rec["grad_keys"])
+            for k, n in zip(rec["grad_keys"], rec["grad_norm"]):
+                assert abs(grads[k].double().norm().item() - n) <= 1e-3 * n + 1e-6, k
+            for k in grads:
+                if "grad/" + k in rec:
+                    g = torch.from_numpy(rec["grad/" + k])
+                    assert (grads[k] - g).abs().max().item() <= 2e-3 * g.abs().max().item() + 1e-6, k
+    assert np.allclose(losses, rec["losses"], rtol=1e-5)
+    for v, n in zip(m.state_dict().values(), rec["wN_norm"]):
+        assert abs(v.double().norm().item() - n) <= 1e-5 * n + 1e-7
+    m.eval()
+    with torch.no_grad():
+        oe = m(x)
+    assert rel_l2(oe, rec["logits_eval"]) < 1e-4
+    mask = oracle.argmax_mask(oe) if classes > 1 else oracle.sigmoid_mask(oe)
+    assert (mask.numpy() != rec["mask_eval"]).mean() < 1e-3
+
+
+def test_cifar_model_matches_reference(oracle):
+    rec = load_golden("cifar_uresnet4_nosu")
+    torch.manual_seed(0)
+    m = oracle.UResNet4_No_SU(10, 3, scale=3)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(rec["keys"])
+    assert [_sha(v) for v in sd.values()] == list(rec["w0_sha"])
+    m.train()
+    x, y = torch.from_numpy(rec["x"]), torch.from_numpy(rec["target"])
+    opt = torch.optim.SGD(m.parameters(), lr=0.01)
+    losses = []
+    for s in range(len(rec["losses"])):
+        loss, out = oracle.cls_train_step(m, opt, x, y)
+        losses.append(loss.item())
+        if s == 0:
+            assert rel_l2(out, rec["logits"]) < 1e-5
+            nograd = [k for k, p in m.named_parameters() if p.grad is None]
+            assert nograd == list(rec["nograd_keys"])       # U_Net.up4.* never receives a gradient
+    assert np.allclose(losses, rec["losses"], rtol=1e-4)
