@@ -1,0 +1,210 @@
+/* liburesnet_hip.so -- C ABI of the MI355X (gfx950) U-ResNet hot path.
+ *
+ * The reference (Nanlingxq/U-ResNet) is pure PyTorch: it has no FFI of its own, every
+ * "kernel" is an ATen dispatch issued by a torch.nn layer.  Each entry point below
+ * therefore cites the reference line whose ATen op it replaces.  Paths are relative to
+ * the reference root; S/C = Segmentation/Cityscapes/modules/U_ResNet.py,
+ * C/C = Classification/modules/U_ResNet_CIFAR.py.
+ *
+ * Conventions
+ *  - Every activation tensor is NHWC ("channels last") in device memory.  `ld` arguments
+ *    are the pixel pitch in elements (>= channels), so a channel slice of a wider concat
+ *    buffer can be read or written in place.
+ *  - dtype selects the activation storage type (UR_F32 or UR_BF16).  Parameters, their
+ *    gradients, batch-norm statistics and loss values are always fp32.
+ *  - The caller owns every buffer including workspaces; the library allocates nothing and
+ *    keeps no mutable global state besides the thread-local error string.
+ *  - All work is enqueued on the given stream (hipStream_t passed as void*); no call
+ *    synchronises the device.
+ *  - Return value: 0 on success, a negative UR_ERR_* code otherwise; ur_last_error()
+ *    returns the message of the calling thread's last failure.
+ */
+#ifndef URESNET_HIP_H
+#define URESNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UR_OK 0
+#define UR_ERR_INVALID (-1)
+#define UR_ERR_LAUNCH (-2)
+
+#define UR_F32 0
+#define UR_BF16 1
+
+typedef void* ur_stream_t;
+
+int ur_version(void);
+const char* ur_last_error(void);
+
+/* ---------------------------------------------------------------- dense convolution
+ * Geometry of one nn.Conv2d(groups=1) call.  Replaces aten::convolution /
+ * convolution_backward issued by S/C:94,97 (DoubleConv), S/C:140,143,151 (BasicBlock),
+ * S/C:230 (7x7 stem), S/C:50,79,132 (1x1 heads), C/C:550 (5x5 convert), and nn.Linear
+ * (C/C:549, as a 1x1 convolution on a 1x1 map). */
+typedef struct ur_conv_desc {
+    int dtype;                 /* UR_F32 | UR_BF16 */
+    int n, h, w, cin;          /* input  NHWC */
+    int oh, ow, cout;          /* output NHWC */
+    int kh, kw, stride, pad;
+    int in_ld, out_ld;         /* pixel pitch of the input / output buffers (elements) */
+} ur_conv_desc;
+
+#define UR_PACK_FWD 0          /* OIHW fp32 -> [cout][Kpad], k = (ky,kx,ci)              */
+#define UR_PACK_DGRAD 1        /* OIHW fp32 -> [cin ][Kpad], k = (ky,kx,co)              */
+#define UR_PACK_CONVT_FWD 2    /* (cin,cout,2,2) fp32 -> [(dy,dx,co)][Kpad], k = ci      */
+#define UR_PACK_CONVT_DGRAD 3  /* (cin,cout,2,2) fp32 -> [ci][Kpad], k = (dy,dx,co)      */
+
+/* number of elements (of the activation dtype) of a packed weight matrix */
+size_t ur_conv2d_packed_elems(const ur_conv_desc* d, int mode);
+int ur_conv2d_pack_weight(const float* w, void* packed, const ur_conv_desc* d, int mode, ur_stream_t s);
+
+/* y = conv(x) (+bias).  If stats != NULL the kernel also emits per-channel partial sums
+ * (sum, sum of squares) of the fp32 results: stats[ur_conv2d_stats_rows(d)][cout][2]. */
+int ur_conv2d_stats_rows(const ur_conv_desc* d);
+int ur_conv2d_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, float* stats,
+                  const ur_conv_desc* d, ur_stream_t s);
+/* dx = conv_backward_input(dy) */
+int ur_conv2d_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const ur_conv_desc* d, ur_stream_t s);
+/* dw (fp32, OIHW) = conv_backward_weight(x, dy); deterministic split-K through `workspace` */
+size_t ur_conv2d_wgrad_workspace(const ur_conv_desc* d);
+int ur_conv2d_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
+                    const ur_conv_desc* d, ur_stream_t s);
+
+/* ---------------------------------------------------------------- ConvTranspose2d(k=2, s=2) + bias
+ * Replaces aten::conv_transpose2d of `Up.up` (S/C:113,117).  d describes the transposed
+ * convolution itself: input (n,h,w,cin) -> output (n,2h,2w,cout); kh=kw=stride=2, pad=0.
+ * Weight layout is PyTorch's (cin, cout, 2, 2). */
+int ur_convT2x2_fwd(const void* x, const void* w_packed, const float* bias, void* y, const ur_conv_desc* d,
+                    ur_stream_t s);
+int ur_convT2x2_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const ur_conv_desc* d, ur_stream_t s);
+size_t ur_convT2x2_wgrad_workspace(const ur_conv_desc* d);
+int ur_convT2x2_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
+                      const ur_conv_desc* d, ur_stream_t s);
+
+/* per-channel column sum of an NHWC tensor: out[c] = sum_rows x[row][c] (bias gradients of
+ * S/C:50,79,113,132).  workspace: ur_colsum_workspace(rows, c) bytes. */
+size_t ur_colsum_workspace(long long rows, int c);
+int ur_colsum(const void* x, int dtype, long long rows, int c, int ld, float* out, void* workspace,
+              size_t ws_bytes, ur_stream_t s);
+
+/* ---------------------------------------------------------------- grouped / depthwise 3x3 (stride 1, pad 1)
+ * EUCB depthwise conv (S/C:44, groups=C, cpg=1) and EUCB* grouped conv (S/C:67,73,
+ * groups=C/4, cpg=4).  Weights stay in PyTorch layout (C, cpg, 3, 3) fp32. */
+int ur_gconv3x3_fwd(const void* x, const float* w, void* y, int dtype, int n, int h, int w_, int c, int cpg,
+                    ur_stream_t s);
+int ur_gconv3x3_dgrad(const void* dy, const float* w, void* dx, int dtype, int n, int h, int w_, int c, int cpg,
+                      ur_stream_t s);
+size_t ur_gconv3x3_wgrad_workspace(int n, int h, int w_, int c, int cpg);
+int ur_gconv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, int dtype,
+                      int n, int h, int w_, int c, int cpg, ur_stream_t s);
+
+/* ---------------------------------------------------------------- BatchNorm2d (+ReLU, +residual add)
+ * Replaces native_batch_norm / relu_ / add_ of S/C:95-96,98-99,141-142,144,152,157-158,
+ * 130-131 and their backward.  Training statistics follow PyTorch: biased variance for
+ * normalisation, unbiased for running_var, running = (1-momentum)*running + momentum*batch. */
+size_t ur_bn_stats_rows(long long rows, int c);          /* rows of partials ur_bn_stats writes */
+int ur_bn_stats(const void* y, int dtype, long long rows, int c, float* partial, ur_stream_t s);
+/* reduce partial[nparts][c][2] -> mean, invstd; update running stats (and increment the
+ * num_batches_tracked counter) where the pointers are non-NULL */
+int ur_bn_finalize(const float* partial, int nparts, long long count, int c, float eps, float momentum,
+                   float* mean, float* invstd, float* running_mean, float* running_var,
+                   long long* num_batches_tracked, ur_stream_t s);
+/* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
+int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int c, float eps, float* mean,
+                       float* invstd, ur_stream_t s);
+/* z = act((y-mean)*invstd*gamma + beta (+ residual));  act: 0 none, 1 relu */
+int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const void* residual, int act, void* z, int dtype, long long rows, int c, ur_stream_t s);
+/* backward pass 1: partial[nparts][c][2] = (sum g, sum g*xhat), g = dz * (z > 0 if act) */
+int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
+                         int act, int dtype, long long rows, int c, float* partial, ur_stream_t s);
+/* sums[c][2] = reduce(partial); dgamma = sums[.,1]; dbeta = sums[.,0] */
+int ur_bn_bwd_finalize(const float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
+                       ur_stream_t s);
+/* backward pass 2: dy = gamma*invstd*(g - sums0/count - xhat*sums1/count); dres = g (optional).
+ * eval != 0 treats the statistics as constants: dy = gamma*invstd*g. */
+int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
+                        const float* gamma, const float* sums, int act, int eval, void* dy, void* dres,
+                        int dtype, long long rows, int c, ur_stream_t s);
+
+/* ---------------------------------------------------------------- spatial ops
+ * MaxPool2d(2,2) (S/C:105), bilinear Upsample(scale, align_corners=False) (S/C:43,66,362;
+ * C/C:303), F.avg_pool2d(k) (C/C:572), F.pad + torch.cat (S/C:121-124, S/C:280). */
+int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, int h, int w, int c, ur_stream_t s);
+int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int n, int h, int w, int c,
+                      ur_stream_t s);
+int ur_upsample_bilinear_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c, int scale,
+                             ur_stream_t s);
+int ur_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int n, int h, int w, int c, int scale,
+                             ur_stream_t s);
+int ur_avgpool_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c, int k, ur_stream_t s);
+int ur_avgpool_bwd(const void* dy, void* dx, int dtype, int n, int h, int w, int c, int k, ur_stream_t s);
+/* dst[n][y+pad_t][x+pad_l][dst_coff .. dst_coff+c) = src[n][y][x][src_coff .. +c);  the rest of
+ * dst's channel window is zero-filled where padding applies (negative pads crop). */
+int ur_copy_channels(const void* src, int src_ld, int src_coff, int sh, int sw, void* dst, int dst_ld,
+                     int dst_coff, int dh, int dw, int pad_t, int pad_l, int n, int c, int dtype,
+                     ur_stream_t s);
+/* general channel shuffle (S/C:6-15): out[.., j*groups + i] = x[.., i*(c/groups) + j] */
+int ur_channel_shuffle(const void* x, void* y, int dtype, long long rows, int c, int groups, ur_stream_t s);
+/* stand-alone activations of act_layer (S/C:17-34); backward takes the forward INPUT x */
+#define UR_ACT_NONE 0
+#define UR_ACT_RELU 1
+#define UR_ACT_RELU6 2
+#define UR_ACT_LEAKYRELU 3
+#define UR_ACT_GELU 4
+#define UR_ACT_HSWISH 5
+int ur_act_fwd(const void* x, void* y, int dtype, long long count, int act, float slope, ur_stream_t s);
+int ur_act_bwd(const void* dy, const void* x, void* dx, int dtype, long long count, int act, float slope,
+               ur_stream_t s);
+/* a += b (gradient accumulation at forks), elementwise over `count` elements */
+int ur_add_inplace(void* a, const void* b, int dtype, long long count, ur_stream_t s);
+/* layout / dtype conversion at the model boundary */
+int ur_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int h, int w,
+                    ur_stream_t s);
+int ur_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int h, int w,
+                    ur_stream_t s);
+
+/* ---------------------------------------------------------------- losses and masks
+ * CrossEntropyLoss(ignore_index) (train_UResNetAblitionStudy.py:66-67, CNN-CIFAR10.py:129),
+ * BCEWithLogitsLoss (Ice-Seg/TrainingCode.py:97), argmax(1) (train_UResNetAblitionStudy.py:73),
+ * sigmoid(x) > 0.5 (Ice-Seg/TrainingCode.py:132). */
+/* workspace (bytes) for the loss reductions over n rows / elements */
+size_t ur_loss_workspace(long long n);
+/* Forward: lse[rows] = log-sum-exp per row; out3 = {sum of NLL over valid rows, number of valid
+ * rows, mean}.  Rows whose target equals ignore_index (or lies outside [0, classes)) are skipped. */
+int ur_ce_fwd(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
+              long long ignore_index, float* lse, float* out3, void* workspace, size_t ws_bytes, ur_stream_t s);
+/* Backward: dlogits = (softmax - onehot) * gout[0] / count[0] on valid rows, 0 elsewhere.  count is
+ * read from device memory (out3 + 1 of the forward, or a globally reduced copy); gout may be NULL (1). */
+int ur_ce_bwd(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
+              long long ignore_index, const float* lse, const float* count, const float* gout, void* dlogits,
+              int dld, ur_stream_t s);
+/* BCEWithLogits, mean over all elements: out3 = {sum, count, mean} */
+int ur_bce_fwd(const void* logits, int dtype, const float* target, long long count, float* out3, void* workspace,
+               size_t ws_bytes, ur_stream_t s);
+int ur_bce_bwd(const void* logits, int dtype, const float* target, long long count, const float* gout,
+               void* dlogits, ur_stream_t s);
+/* first-maximum argmax over the channel axis (bit-exact class map given identical logits) */
+int ur_argmax_channels(const void* logits, int dtype, long long rows, int classes, int ld, int64_t* out,
+                       ur_stream_t s);
+/* out = sigmoid(x) > 0.5 evaluated in fp32 as the reference writes it */
+int ur_sigmoid_mask(const void* logits, int dtype, long long count, uint8_t* out, ur_stream_t s);
+
+/* ---------------------------------------------------------------- optimisers (multi-tensor)
+ * optim.Adam(lr) (train_UResNetAblitionStudy.py:203) and optim.SGD(lr) (CNN-CIFAR10.py:130).
+ * ptrs: device array of ntensors*{4|2} pointers (param, grad, exp_avg, exp_avg_sq | param, grad);
+ * sizes: device array of element counts; total = sum(sizes). */
+int ur_adam_multi(const void* const* ptrs, const long long* sizes, int ntensors, long long max_size, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  ur_stream_t s);
+int ur_sgd_multi(const void* const* ptrs, const long long* sizes, int ntensors, long long max_size, float lr,
+                 float weight_decay, float grad_scale, ur_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

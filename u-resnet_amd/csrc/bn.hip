@@ -1,0 +1,344 @@
+// BatchNorm2d (+ReLU, +residual add) forward / backward and per-channel column reductions.
+// All tensors are dense NHWC viewed as [rows][C]; every kernel is HBM-bound: one coalesced
+// pass, 16-byte (bf16x8 / float4) accesses where C allows, fp32 arithmetic, and per-channel
+// reductions done as thread-private sums -> LDS tree over the row slots of a workgroup ->
+// one partial row per workgroup (summed later in a fixed order: reproducible, no atomics).
+#include "ur_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------ column reduction skeleton
+// Thread (slot, colgroup) walks rows slot, slot+S, ... of its VEC channels and accumulates
+// NV values per channel; workgroup writes partial[blockIdx.x][C][NV].
+template <int VEC, int NV, typename Op>
+__device__ __forceinline__ void colreduce_body(const Op& op, long long rows, int C, float* __restrict__ partial) {
+    __shared__ float red[NT * VEC * NV];
+    const int cq = (C + VEC - 1) / VEC;                 // column groups in total
+    const int cqb = cq < NT ? cq : NT;                  // column groups handled per pass
+    const int slots = NT / cqb;
+    const int tid = threadIdx.x;
+    const int slot = tid / cqb, cg = tid - slot * cqb;
+    for (int cbase = 0; cbase < cq; cbase += cqb) {
+        const int col = (cbase + cg) * VEC;
+        float acc[VEC * NV];
+#pragma unroll
+        for (int i = 0; i < VEC * NV; ++i) acc[i] = 0.f;
+        if (slot < slots && col < C) {
+            for (long long r = (long long)blockIdx.x * slots + slot; r < rows; r += (long long)gridDim.x * slots)
+                op(r, col, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC * NV; ++i) red[i * NT + tid] = acc[i];
+        __syncthreads();
+        if (tid < cqb && col < C) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if (col + v < C) {
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        float s = 0.f;
+                        for (int sl = 0; sl < slots; ++sl) s += red[(v * NV + k) * NT + sl * cqb + tid];
+                        partial[((size_t)blockIdx.x * C + col + v) * NV + k] = s;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int VEC> struct RowVec {
+    float v[VEC];
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (VEC == 4) { float4 f = ur_load4(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+        else v[0] = ur_to_float(*p);
+    }
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(NT) void bn_stats_kernel(const T* __restrict__ y, long long rows, int C,
+                                                      float* __restrict__ partial) {
+    auto op = [&](long long r, int col, float* acc) {
+        RowVec<T, VEC> a; a.load(y + r * C + col);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { acc[v * 2] += a.v[v]; acc[v * 2 + 1] += a.v[v] * a.v[v]; }
+    };
+    colreduce_body<VEC, 2>(op, rows, C, partial);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, long long rows, int C, int ld,
+                                                    float* __restrict__ partial) {
+    auto op = [&](long long r, int col, float* acc) {
+        RowVec<T, VEC> a; a.load(x + r * ld + col);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += a.v[v];
+    };
+    colreduce_body<VEC, 1>(op, rows, C, partial);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                           const T* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, int act, long long rows,
+                                                           int C, float* __restrict__ partial) {
+    auto op = [&](long long r, int col, float* acc) {
+        RowVec<T, VEC> g, yy, zz;
+        g.load(dz + r * C + col); yy.load(y + r * C + col);
+        if (act) zz.load(z + r * C + col);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float gv = (act && !(zz.v[v] > 0.f)) ? 0.f : g.v[v];
+            float xh = (yy.v[v] - mean[col + v]) * invstd[col + v];
+            acc[v * 2] += gv; acc[v * 2 + 1] += gv * xh;
+        }
+    };
+    colreduce_body<VEC, 2>(op, rows, C, partial);
+}
+
+// out[c][k] = sum_p partial[p][c][k] in double; optional mean/invstd/running-stat epilogue
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, long long count, int C, float eps,
+                                   float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += partial[((size_t)p * C + c) * 2];
+        s2 += partial[((size_t)p * C + c) * 2 + 1];
+    }
+    double m = s1 / (double)count;
+    double var = s2 / (double)count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C,
+                                       float eps, float* __restrict__ mean, float* __restrict__ invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = 1.f / sqrtf(rvar[c] + eps);
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, int NV,
+                                    float* __restrict__ sums, float* __restrict__ o0, float* __restrict__ o1) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+        for (int p = 0; p < nparts; ++p) s += partial[((size_t)p * C + c) * NV + k];
+        if (sums) sums[(size_t)c * NV + k] = (float)s;
+        if (k == 0 && o0) o0[c] = (float)s;
+        if (k == 1 && o1) o1[c] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------ elementwise passes
+template <typename T> struct EW { static constexpr int V = 4; };
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const T* __restrict__ res, int act,
+                                                        T* __restrict__ z, long long total, int C) {
+    // C % 4 == 0 (checked on the host): a float4 / bf16x4 never straddles a row
+    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * NT * 4) {
+        const int c = (int)(i % C);
+        float4 v = ur_load4(y + i);
+        float4 m = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+        float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = (v.x - m.x) * is.x * g.x + b.x; o.y = (v.y - m.y) * is.y * g.y + b.y;
+        o.z = (v.z - m.z) * is.z * g.z + b.z; o.w = (v.w - m.w) * is.w * g.w + b.w;
+        if (res) { float4 r = ur_load4(res + i); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        if (act) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        ur_store4(z + i, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_act_fwd_scalar_kernel(const T* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const T* __restrict__ res, int act, T* __restrict__ z,
+                                                               long long total, int C) {
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        float o = (ur_to_float(y[i]) - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        if (res) o += ur_to_float(res[i]);
+        if (act) o = fmaxf(o, 0.f);
+        z[i] = ur_from_float<T>(o);
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                              const T* __restrict__ z, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ sums, int act, int eval, float inv_count,
+                                                              T* __restrict__ dy, T* __restrict__ dres, long long total, int C) {
+    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * VEC; i < total;
+         i += (long long)gridDim.x * NT * VEC) {
+        const int c = (int)(i % C);
+        RowVec<T, VEC> g, yy, zz;
+        g.load(dz + i); yy.load(y + i);
+        if (act) zz.load(z + i);
+        float o[VEC], gm[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float gv = (act && !(zz.v[v] > 0.f)) ? 0.f : g.v[v];
+            gm[v] = gv;
+            float k = gamma[c + v] * invstd[c + v];
+            if (eval) o[v] = k * gv;
+            else {
+                float xh = (yy.v[v] - mean[c + v]) * invstd[c + v];
+                o[v] = k * (gv - sums[(c + v) * 2] * inv_count - xh * sums[(c + v) * 2 + 1] * inv_count);
+            }
+        }
+        if constexpr (VEC == 4) {
+            ur_store4(dy + i, make_float4(o[0], o[1], o[2], o[3]));
+            if (dres) ur_store4(dres + i, make_float4(gm[0], gm[1], gm[2], gm[3]));
+        } else {
+            dy[i] = ur_from_float<T>(o[0]);
+            if (dres) dres[i] = ur_from_float<T>(gm[0]);
+        }
+    }
+}
+
+int reduce_grid(long long rows, int C, int vec) {
+    int cq = (C + vec - 1) / vec;
+    int cqb = cq < NT ? cq : NT;
+    int slots = NT / cqb;
+    long long g = (rows + (long long)slots * 8 - 1) / ((long long)slots * 8);     // >= 8 rows per thread
+    if (g < 1) g = 1;
+    if (g > 1024) g = 1024;
+    return (int)g;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+size_t ur_bn_stats_rows(long long rows, int c) { return (size_t)reduce_grid(rows, c, c % 4 == 0 ? 4 : 1); }
+
+int ur_bn_stats(const void* y, int dtype, long long rows, int c, float* partial, ur_stream_t s) {
+    UR_REQUIRE(y && partial && rows > 0 && c > 0, "bn_stats: bad arguments");
+    const bool vec = (c % 4 == 0) && aligned16(y);
+    const int grid = reduce_grid(rows, c, c % 4 == 0 ? 4 : 1);
+    UR_DISPATCH_DTYPE(dtype, {
+        if (vec) hipLaunchKernelGGL((bn_stats_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)y, rows, c, partial);
+        else hipLaunchKernelGGL((bn_stats_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)y, rows, c, partial);
+    });
+    return ur_check_launch("bn_stats");
+}
+
+size_t ur_colsum_workspace(long long rows, int c) {
+    return (size_t)reduce_grid(rows, c, c % 4 == 0 ? 4 : 1) * c * sizeof(float);
+}
+
+int ur_colsum(const void* x, int dtype, long long rows, int c, int ld, float* out, void* workspace, size_t ws_bytes,
+              ur_stream_t s) {
+    UR_REQUIRE(x && out && workspace && rows > 0 && c > 0 && ld >= c, "colsum: bad arguments");
+    UR_REQUIRE(ws_bytes >= ur_colsum_workspace(rows, c), "colsum: workspace too small");
+    const int esz = dtype == UR_BF16 ? 2 : 4;
+    const bool vec = (c % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) % (4 * esz) == 0);
+    const int grid = reduce_grid(rows, c, c % 4 == 0 ? 4 : 1);
+    float* partial = (float*)workspace;
+    UR_DISPATCH_DTYPE(dtype, {
+        if (vec) hipLaunchKernelGGL((colsum_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, rows, c, ld, partial);
+        else hipLaunchKernelGGL((colsum_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, rows, c, ld, partial);
+    });
+    if (int e = ur_check_launch("colsum")) return e;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ur_cdiv(c, 128)), dim3(128), 0, (hipStream_t)s, partial, grid, c, 1,
+                       (float*)nullptr, out, (float*)nullptr);
+    return ur_check_launch("colsum_finalize");
+}
+
+int ur_bn_finalize(const float* partial, int nparts, long long count, int c, float eps, float momentum, float* mean,
+                   float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+                   ur_stream_t s) {
+    UR_REQUIRE(partial && mean && invstd && nparts > 0 && count > 0 && c > 0, "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, count, c,
+                       eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
+    return ur_check_launch("bn_finalize");
+}
+
+int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int c, float eps, float* mean,
+                       float* invstd, ur_stream_t s) {
+    UR_REQUIRE(running_mean && running_var && mean && invstd && c > 0, "bn_eval_prepare: bad arguments");
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, running_mean,
+                       running_var, c, eps, mean, invstd);
+    return ur_check_launch("bn_eval_prepare");
+}
+
+int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const void* residual, int act, void* z, int dtype, long long rows, int c, ur_stream_t s) {
+    UR_REQUIRE(y && mean && invstd && gamma && beta && z && rows > 0 && c > 0, "bn_act_fwd: bad arguments");
+    const long long total = rows * c;
+    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(z) && aligned16(residual) && aligned16(mean) &&
+                     aligned16(invstd) && aligned16(gamma) && aligned16(beta);
+    UR_DISPATCH_DTYPE(dtype, {
+        if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(ur_grid_1d(total / 4, NT)), dim3(NT), 0, (hipStream_t)s,
+                                    (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c);
+        else hipLaunchKernelGGL((bn_act_fwd_scalar_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0, (hipStream_t)s,
+                                (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c);
+    });
+    return ur_check_launch("bn_act_fwd");
+}
+
+int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd, int act,
+                         int dtype, long long rows, int c, float* partial, ur_stream_t s) {
+    UR_REQUIRE(dz && y && mean && invstd && partial && rows > 0 && c > 0, "bn_act_bwd_reduce: bad arguments");
+    UR_REQUIRE(!act || z, "bn_act_bwd_reduce: activation mask needs z");
+    const bool vec = (c % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(z);
+    const int grid = reduce_grid(rows, c, c % 4 == 0 ? 4 : 1);
+    UR_DISPATCH_DTYPE(dtype, {
+        if (vec) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
+                                    (const T*)y, (const T*)z, mean, invstd, act, rows, c, partial);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
+                                (const T*)y, (const T*)z, mean, invstd, act, rows, c, partial);
+    });
+    return ur_check_launch("bn_act_bwd_reduce");
+}
+
+int ur_bn_bwd_finalize(const float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
+                       ur_stream_t s) {
+    UR_REQUIRE(partial && sums && nparts > 0 && c > 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, c, 2,
+                       sums, dbeta, dgamma);
+    return ur_check_launch("bn_bwd_finalize");
+}
+
+int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
+                        const float* gamma, const float* sums, int act, int eval, void* dy, void* dres, int dtype,
+                        long long rows, int c, ur_stream_t s) {
+    UR_REQUIRE(dz && y && mean && invstd && gamma && dy && rows > 0 && c > 0, "bn_act_bwd_apply: bad arguments");
+    UR_REQUIRE(!act || z, "bn_act_bwd_apply: activation mask needs z");
+    UR_REQUIRE(eval || sums, "bn_act_bwd_apply: training mode needs the reduced sums");
+    const long long total = rows * c;
+    const float inv_count = 1.f / (float)rows;
+    const bool vec = (c % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(z) && aligned16(dy) && aligned16(dres);
+    UR_DISPATCH_DTYPE(dtype, {
+        if (vec) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 4>), dim3(ur_grid_1d(total / 4, NT)), dim3(NT), 0,
+                                    (hipStream_t)s, (const T*)dz, (const T*)y, (const T*)z, mean, invstd, gamma, sums, act,
+                                    eval, inv_count, (T*)dy, (T*)dres, total, c);
+        else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 1>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0, (hipStream_t)s,
+                                (const T*)dz, (const T*)y, (const T*)z, mean, invstd, gamma, sums, act, eval, inv_count,
+                                (T*)dy, (T*)dres, total, c);
+    });
+    return ur_check_launch("bn_act_bwd_apply");
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+// Grouped 3x3 convolutions with 1 or 4 channels per group (EUCB depthwise, EUCB* groups=C/4),
+// stride 1, pad 1, NHWC.  These are bandwidth-bound (<= 36 MAC per loaded element): a direct
+// kernel, one thread per (pixel, 4-channel quad), 8/16-byte coalesced accesses, fp32 math.
+// CPG == 4: the quad is one group (4 in x 4 out).  CPG == 1: the quad is 4 independent channels.
+// Weights stay in PyTorch layout w[c_out][cpg][3][3] fp32 and are read through the cache.
+#include "ur_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// out[a] = sum_{tap,b} in[p + off(tap)][b] * Wt(a, b, tap)
+//   forward       : off = (ky-1, kx-1), Wt = w[q*4+a][b][tap]
+//   backward-data : off = (1-ky, 1-kx), Wt = w[q*4+b][a][tap]
+template <typename T, int CPG, bool DGRAD>
+__global__ __launch_bounds__(NT) void gconv3x3_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                      T* __restrict__ out, int N, int H, int W, int C) {
+    const int Q = C / 4;
+    const long long total = (long long)N * H * W * Q;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int q = (int)(i % Q);
+        const long long pix = i / Q;
+        const int x = (int)(pix % W);
+        const long long t = pix / W;
+        const int y = (int)(t % H), n = (int)(t / H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wq = w + (size_t)q * 4 * CPG * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = DGRAD ? y + 1 - ky : y + ky - 1;
+            if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = DGRAD ? x + 1 - kx : x + kx - 1;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float4 v = ur_load4(in + (((long long)n * H + yy) * W + xx) * C + q * 4);
+                const float vi[4] = {v.x, v.y, v.z, v.w};
+                const int tap = ky * 3 + kx;
+                if constexpr (CPG == 1) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] += vi[a] * wq[a * 9 + tap];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a] += vi[b] * (DGRAD ? wq[(b * 4 + a) * 9 + tap] : wq[(a * 4 + b) * 9 + tap]);
+                }
+            }
+        }
+        ur_store4(out + pix * C + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+}
+
+// Backward-weight: thread (slot, quad) accumulates its quad's CPG*4*9 products over the pixels
+// slot, slot+S, ...; the slots of a workgroup are summed through LDS in a fixed order and each
+// workgroup writes one partial row partial[block][C*CPG*9] (layout = PyTorch weight layout).
+template <typename T, int CPG>
+__global__ __launch_bounds__(NT) void gconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            float* __restrict__ partial, int N, int H, int W, int C) {
+    constexpr int NV = 4 * CPG;                   // values per tap held by a thread
+    __shared__ float red[NT * NV];
+    const int Q = C / 4;
+    const int qb = Q < NT ? Q : NT;
+    const int slots = NT / qb;
+    const int tid = threadIdx.x;
+    const int slot = tid / qb, ql = tid - slot * qb;
+    const long long P = (long long)N * H * W;
+    const size_t wsz = (size_t)C * CPG * 9;
+    for (int qbase = 0; qbase < Q; qbase += qb) {
+        const int q = qbase + ql;
+        float acc[9][NV];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[t][v] = 0.f;
+        if (slot < slots && q < Q) {
+            for (long long pix = (long long)blockIdx.x * slots + slot; pix < P; pix += (long long)gridDim.x * slots) {
+                const int xx0 = (int)(pix % W);
+                const long long t = pix / W;
+                const int yy0 = (int)(t % H), n = (int)(t / H);
+                const float4 g4 = ur_load4(dy + pix * C + q * 4);
+                const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = yy0 + ky - 1;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = xx0 + kx - 1;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        const float4 v4 = ur_load4(x + (((long long)n * H + yy) * W + xx) * C + q * 4);
+                        const float vi[4] = {v4.x, v4.y, v4.z, v4.w};
+                        if constexpr (CPG == 1) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) acc[ky * 3 + kx][a] += g[a] * vi[a];
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) acc[ky * 3 + kx][a * 4 + b] += g[a] * vi[b];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) red[v * NT + tid] = acc[t][v];
+            __syncthreads();
+            if (tid < qb && q < Q) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float s = 0.f;
+                    for (int sl = 0; sl < slots; ++sl) s += red[v * NT + sl * qb + tid];
+                    // v = a (CPG==1) or a*4+b: weight index ((q*4+a)*CPG + b)*9 + t
+                    const int a = CPG == 1 ? v : v >> 2, b = CPG == 1 ? 0 : v & 3;
+                    partial[(size_t)blockIdx.x * wsz + ((size_t)(q * 4 + a) * CPG + b) * 9 + t] = s;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void gconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, long long wsz,
+                                          float* __restrict__ dw) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < wsz; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < nparts; ++p) s += partial[(long long)p * wsz + i];
+        dw[i] = s;
+    }
+}
+
+int wgrad_blocks(long long P, int C) {
+    int Q = C / 4;
+    int qb = Q < NT ? Q : NT;
+    int slots = NT / qb;
+    long long g = (P + (long long)slots * 16 - 1) / ((long long)slots * 16);
+    if (g < 1) g = 1;
+    if (g > 1024) g = 1024;
+    return (int)g;
+}
+
+int check_args(const void* a, const void* b, const void* c, int dtype, int n, int h, int w, int ch, int cpg) {
+    UR_REQUIRE(a && b && c, "gconv3x3: null pointer");
+    UR_REQUIRE(n > 0 && h > 0 && w > 0 && ch > 0, "gconv3x3: non-positive dimension");
+    UR_REQUIRE(cpg == 1 || cpg == 4, "gconv3x3: channels per group must be 1 or 4 (got %d)", cpg);
+    UR_REQUIRE(ch % 4 == 0, "gconv3x3: channel count %d is not a multiple of 4", ch);
+    const int es = dtype == UR_BF16 ? 2 : 4;
+    UR_REQUIRE(((uintptr_t)a % (4 * es)) == 0 && ((uintptr_t)c % (4 * es)) == 0, "gconv3x3: misaligned tensor");
+    return UR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ur_gconv3x3_fwd(const void* x, const float* w, void* y, int dtype, int n, int h, int w_, int c, int cpg, ur_stream_t s) {
+    if (int e = check_args(x, w, y, dtype, n, h, w_, c, cpg)) return e;
+    const long long total = (long long)n * h * w_ * (c / 4);
+    const int grid = ur_grid_1d(total, NT);
+    UR_DISPATCH_DTYPE(dtype, {
+        if (cpg == 1) hipLaunchKernelGGL((gconv3x3_kernel<T, 1, false>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, w, (T*)y, n, h, w_, c);
+        else hipLaunchKernelGGL((gconv3x3_kernel<T, 4, false>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, w, (T*)y, n, h, w_, c);
+    });
+    return ur_check_launch("gconv3x3_fwd");
+}
+
+int ur_gconv3x3_dgrad(const void* dy, const float* w, void* dx, int dtype, int n, int h, int w_, int c, int cpg, ur_stream_t s) {
+    if (int e = check_args(dy, w, dx, dtype, n, h, w_, c, cpg)) return e;
+    const long long total = (long long)n * h * w_ * (c / 4);
+    const int grid = ur_grid_1d(total, NT);
+    UR_DISPATCH_DTYPE(dtype, {
+        if (cpg == 1) hipLaunchKernelGGL((gconv3x3_kernel<T, 1, true>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dy, w, (T*)dx, n, h, w_, c);
+        else hipLaunchKernelGGL((gconv3x3_kernel<T, 4, true>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dy, w, (T*)dx, n, h, w_, c);
+    });
+    return ur_check_launch("gconv3x3_dgrad");
+}
+
+size_t ur_gconv3x3_wgrad_workspace(int n, int h, int w_, int c, int cpg) {
+    return (size_t)wgrad_blocks((long long)n * h * w_, c) * c * cpg * 9 * sizeof(float);
+}
+
+int ur_gconv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, int dtype, int n, int h,
+                      int w_, int c, int cpg, ur_stream_t s) {
+    if (int e = check_args(x, dw, dy, dtype, n, h, w_, c, cpg)) return e;
+    UR_REQUIRE(workspace && ws_bytes >= ur_gconv3x3_wgrad_workspace(n, h, w_, c, cpg), "gconv3x3_wgrad: workspace too small");
+    const int grid = wgrad_blocks((long long)n * h * w_, c);
+    float* partial = (float*)workspace;
+    UR_DISPATCH_DTYPE(dtype, {
+        if (cpg == 1) hipLaunchKernelGGL((gconv3x3_wgrad_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, (const T*)dy, partial, n, h, w_, c);
+        else hipLaunchKernelGGL((gconv3x3_wgrad_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, (const T*)dy, partial, n, h, w_, c);
+    });
+    if (int e = ur_check_launch("gconv3x3_wgrad")) return e;
+    const long long wsz = (long long)c * cpg * 9;
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3(ur_grid_1d(wsz, 256)), dim3(256), 0, (hipStream_t)s, partial, grid, wsz, dw);
+    return ur_check_launch("gconv3x3_wgrad_reduce");
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// Backward-weight convolution as an MFMA GEMM whose reduction runs over pixels.
+//
+//   dW[o][(tap,i)] = sum_pix dV[pix][o] * U[pix (+) tap][i]
+// rows  = channels of the output-gradient tensor dV (tile 128),
+// cols  = (tap, channel of the input tensor U), channel fastest (tile 128),
+// K     = pixels of dV, processed in slices of BK pixels; the pixel range is split over
+//         gridDim.y workgroups whose fp32 partial tiles go to a workspace slab each, and a
+//         second kernel sums the slabs in a fixed order (bitwise reproducible, no atomics)
+//         while transposing (tap,i) -> PyTorch's [o][i][ky][kx].
+// Both operands sit in LDS as [pixel][channel] (the NHWC order they are loaded in).  The
+// MFMA wants 8 consecutive k (= pixels) per lane, so bf16 fragments are fetched with the
+// transposing LDS read ds_read_b64_tr_b16; fp32 uses v_mfma_f32_32x32x2_f32, whose one-k-per
+// -lane operands are plain row reads of that layout.
+#include "ur_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int TM = 128, TN = 128, NTHREADS = 256;
+
+struct WgradParams {
+    const void* u;       // input tensor   (N, H, W, I), pitch u_ld
+    const void* dv;      // output gradient (N, OH, OW, O), pitch dv_ld
+    float* ws;           // [nsplit][O][Kred]
+    int N, H, W, I, OH, OW, O;
+    int kh, kw, stride, pad;
+    int Kred;            // kh*kw*I
+    int P;               // N*OH*OW
+    int u_ld, dv_ld;
+    int stages_per_split;
+    int ntiles;
+};
+
+template <typename T> struct WgCfg;
+template <> struct WgCfg<bf16_t> { static constexpr int BK = 64, PITCH = 160, VW = 8; };   // 256 B row + 64 B pad
+template <> struct WgCfg<float> { static constexpr int BK = 32, PITCH = 132, VW = 4; };    // 512 B row + 16 B pad
+
+template <typename T, int V> struct Chunk;          // V consecutive channels held in registers
+template <> struct Chunk<bf16_t, 8> {
+    bf16x8_t v;
+    __device__ __forceinline__ void zero() { v = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8_t*>(p); }
+    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<bf16x8_t*>(p) = v; }
+};
+template <> struct Chunk<float, 4> {      // fp32 moves 16 bytes per chunk as well (4 channels)
+    float4 a;
+    __device__ __forceinline__ void zero() { a = make_float4(0, 0, 0, 0); }
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = a; }
+};
+template <typename T> struct Chunk<T, 1> {
+    T v;
+    __device__ __forceinline__ void zero() { v = ur_from_float<T>(0.f); }
+    __device__ __forceinline__ void load(const T* p) { v = *p; }
+    __device__ __forceinline__ void store(T* p) const { *p = v; }
+};
+
+template <typename T, int VA, int VB>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int BK = WgCfg<T>::BK, PITCH = WgCfg<T>::PITCH;
+    __shared__ __attribute__((aligned(16))) T As[BK * PITCH];
+    __shared__ __attribute__((aligned(16))) T Bs[BK * PITCH];
+
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int o0 = mt * TM, n0 = nt * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;           // 2x2 waves, 64x64 each
+    const T* __restrict__ U = static_cast<const T*>(p.u);
+    const T* __restrict__ DV = static_cast<const T*>(p.dv);
+
+    // loader geometry: chunks of V channels; (TM/V) chunk-columns per pixel row
+    constexpr int ACOLS = TM / VA, AROWS_PER_PASS = NTHREADS / ACOLS, APASS = BK / AROWS_PER_PASS;
+    constexpr int BCOLS = TN / VB, BROWS_PER_PASS = NTHREADS / BCOLS, BPASS = BK / BROWS_PER_PASS;
+    const int a_col = (tid % ACOLS) * VA, a_row = tid / ACOLS;
+    const int b_col = (tid % BCOLS) * VB, b_row = tid / BCOLS;
+    const bool a_ok = (o0 + a_col) < p.O;              // O % VA == 0 whenever VA > 1
+    // this thread's B column is a fixed (tap, channel)
+    const int bn = n0 + b_col;
+    const bool b_ok = bn < p.Kred;
+    int b_ky = 0, b_kx = 0, b_ci = 0;
+    if (b_ok) { int tap = bn / p.I; b_ci = bn - tap * p.I; b_ky = tap / p.kw; b_kx = tap - b_ky * p.kw; }
+
+    Chunk<T, VA> pa[APASS];
+    Chunk<T, VB> pb[BPASS];
+    const int stage0 = split * p.stages_per_split;
+    int nstages = (p.P + BK - 1) / BK - stage0;
+    if (nstages > p.stages_per_split) nstages = p.stages_per_split;
+
+    auto gather = [&](int st) {
+        const int pix0 = (stage0 + st) * BK;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            int pix = pix0 + a_row + i * AROWS_PER_PASS;
+            if (a_ok && pix < p.P) pa[i].load(DV + (size_t)pix * p.dv_ld + o0 + a_col);
+            else pa[i].zero();
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            int pix = pix0 + b_row + i * BROWS_PER_PASS;
+            int pc = pix < p.P ? pix : 0;
+            int img = pc / (p.OH * p.OW);
+            int rem = pc - img * (p.OH * p.OW);
+            int oy = rem / p.OW, ox = rem - oy * p.OW;
+            int iy = oy * p.stride + b_ky - p.pad, ix = ox * p.stride + b_kx - p.pad;
+            bool ok = b_ok && pix < p.P && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            if (ok) pb[i].load(U + ((size_t)(img * p.H + iy) * p.W + ix) * p.u_ld + b_ci);
+            else pb[i].zero();
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) pa[i].store(&As[(a_row + i * AROWS_PER_PASS) * PITCH + a_col]);
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) pb[i].store(&Bs[(b_row + i * BROWS_PER_PASS) * PITCH + b_col]);
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (nstages > 0) gather(0);
+    for (int st = 0; st < nstages; ++st) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (st + 1 < nstages) gather(st + 1);
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+            // transposing read: 16-lane group g covers pixels [8*(g>>1) .. +3] x channels [16*(g&1) .. +15]
+            const int g = lane >> 4, li = lane & 15;
+            const int t_pix = 8 * (g >> 1) + (li >> 2), t_ch = 16 * (g & 1) + 4 * (li & 3);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8_t af[2], bfr[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const T* q = &As[(ks * 16 + t_pix) * PITCH + wm * 64 + a * 32 + t_ch];
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)q);
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + 4 * PITCH));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                    s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    af[a] = __builtin_bit_cast(bf16x8_t, both);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const T* q = &Bs[(ks * 16 + t_pix) * PITCH + wn * 64 + b * 32 + t_ch];
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)q);
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + 4 * PITCH));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                    s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bfr[b] = __builtin_bit_cast(bf16x8_t, both);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            }
+        } else {
+            const int lrow = lane & 31, lhalf = lane >> 5;
+#pragma unroll 4
+            for (int kk = 0; kk < BK; kk += 2) {
+                float af[2], bfr[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[a] = As[(kk + lhalf) * PITCH + wm * 64 + a * 32 + lrow];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bfr[b] = Bs[(kk + lhalf) * PITCH + wn * 64 + b * 32 + lrow];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    // partial tile -> this split's slab
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    float* slab = p.ws + (size_t)split * p.O * p.Kred;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 64 + b * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                if (o < p.O && n < p.Kred) slab[(size_t)o * p.Kred + n] = acc[a][b][r];
+            }
+        }
+}
+
+// dw[o][i][tap] = sum_s ws[s][o][tap*I + i]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int O, int I, int taps,
+                                    int nsplit) {
+    const long long per = (long long)O * I * taps;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < per;
+         idx += (long long)gridDim.x * blockDim.x) {
+        int o = (int)(idx / ((long long)I * taps));
+        int rem = (int)(idx - (long long)o * I * taps);
+        int tap = rem / I, i = rem - tap * I;           // read order: (tap, i) contiguous
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * per + idx];
+        dw[((long long)o * I + i) * taps + tap] = s;
+    }
+}
+
+struct WgradPlan { int mtiles, ntiles, nsplit, stages_per_split; };
+
+template <typename T>
+WgradPlan plan_for(int O, int Kred, long long P) {
+    constexpr int BK = WgCfg<T>::BK;
+    WgradPlan pl;
+    pl.mtiles = ur_cdiv(O, TM);
+    pl.ntiles = ur_cdiv(Kred, TN);
+    long long stages = (P + BK - 1) / BK;
+    long long tiles = (long long)pl.mtiles * pl.ntiles;
+    long long want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU in total
+    if (want > stages) want = stages;
+    if (want < 1) want = 1;
+    pl.stages_per_split = (int)((stages + want - 1) / want);
+    pl.nsplit = (int)((stages + pl.stages_per_split - 1) / pl.stages_per_split);
+    return pl;
+}
+
+WgradPlan plan_dtype(int dtype, int O, int Kred, long long P) {
+    return dtype == UR_BF16 ? plan_for<bf16_t>(O, Kred, P) : plan_for<float>(O, Kred, P);
+}
+
+template <typename T>
+int launch_wgrad(WgradParams& p, float* dw, hipStream_t st) {
+    WgradPlan pl = plan_for<T>(p.O, p.Kred, p.P);
+    p.stages_per_split = pl.stages_per_split;
+    p.ntiles = pl.ntiles;
+    dim3 grid(pl.mtiles * pl.ntiles, pl.nsplit);
+    constexpr int VW = WgCfg<T>::VW;
+    const bool va = (p.O % VW == 0) && (p.dv_ld % VW == 0) && ((uintptr_t)p.dv % 16 == 0);
+    const bool vb = (p.I % VW == 0) && (p.u_ld % VW == 0) && ((uintptr_t)p.u % 16 == 0);
+    if (va && vb) hipLaunchKernelGGL((conv_wgrad_kernel<T, VW, VW>), grid, dim3(NTHREADS), 0, st, p);
+    else if (va) hipLaunchKernelGGL((conv_wgrad_kernel<T, VW, 1>), grid, dim3(NTHREADS), 0, st, p);
+    else if (vb) hipLaunchKernelGGL((conv_wgrad_kernel<T, 1, VW>), grid, dim3(NTHREADS), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 1, 1>), grid, dim3(NTHREADS), 0, st, p);
+    if (int e = ur_check_launch("conv_wgrad")) return e;
+    const long long per = (long long)p.O * p.Kred;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ur_grid_1d(per, 256)), dim3(256), 0, st, p.ws, dw, p.O, p.I,
+                       p.kh * p.kw, pl.nsplit);
+    return ur_check_launch("wgrad_reduce");
+}
+
+int check_common(const ur_conv_desc* d, const void* a, const void* b, const float* dw, const void* ws) {
+    UR_REQUIRE(d != nullptr, "wgrad: null descriptor");
+    UR_REQUIRE(d->dtype == UR_F32 || d->dtype == UR_BF16, "wgrad: bad dtype %d", d->dtype);
+    UR_REQUIRE(a && b && dw && ws, "wgrad: null pointer");
+    UR_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->oh > 0 && d->ow > 0,
+               "wgrad: non-positive dimension");
+    UR_REQUIRE(d->in_ld >= d->cin && d->out_ld >= d->cout, "wgrad: pitch smaller than channel count");
+    UR_REQUIRE((long long)d->n * d->h * d->w < (1LL << 31) && (long long)d->n * d->oh * d->ow < (1LL << 31),
+               "wgrad: more than 2^31 pixels");
+    return UR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ur_conv2d_wgrad_workspace(const ur_conv_desc* d) {
+    if (!d) return 0;
+    const int Kred = d->kh * d->kw * d->cin;
+    WgradPlan pl = plan_dtype(d->dtype, d->cout, Kred, (long long)d->n * d->oh * d->ow);
+    return (size_t)pl.nsplit * d->cout * Kred * sizeof(float);
+}
+
+int ur_conv2d_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
+                    ur_stream_t s) {
+    if (int e = check_common(d, x, dy, dw, workspace)) return e;
+    UR_REQUIRE(ws_bytes >= ur_conv2d_wgrad_workspace(d), "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes,
+               ur_conv2d_wgrad_workspace(d));
+    WgradParams p{};
+    p.u = x; p.dv = dy; p.ws = (float*)workspace;
+    p.N = d->n; p.H = d->h; p.W = d->w; p.I = d->cin; p.OH = d->oh; p.OW = d->ow; p.O = d->cout;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.Kred = d->kh * d->kw * d->cin; p.P = d->n * d->oh * d->ow;
+    p.u_ld = d->in_ld; p.dv_ld = d->out_ld;
+    UR_DISPATCH_DTYPE(d->dtype, return launch_wgrad<T>(p, dw, (hipStream_t)s));
+}
+
+// ConvTranspose2d(k=2,s=2): dW[ci][co][dy][dx] = sum x[n,y,x,ci] * dout[n,2y+dy,2x+dx,co]
+// = backward-weight of the 2x2 stride-2 convolution that maps dout-shaped tensors to x-shaped ones.
+size_t ur_convT2x2_wgrad_workspace(const ur_conv_desc* d) {
+    if (!d) return 0;
+    const int Kred = 4 * d->cout;
+    WgradPlan pl = plan_dtype(d->dtype, d->cin, Kred, (long long)d->n * d->h * d->w);
+    return (size_t)pl.nsplit * d->cin * Kred * sizeof(float);
+}
+
+int ur_convT2x2_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
+                      const ur_conv_desc* d, ur_stream_t s) {
+    if (int e = check_common(d, x, dy, dw, workspace)) return e;
+    UR_REQUIRE(d->kh == 2 && d->kw == 2 && d->stride == 2 && d->pad == 0 && d->oh == 2 * d->h && d->ow == 2 * d->w,
+               "convT2x2_wgrad: geometry must be 2x2 stride 2 pad 0 with a 2x output");
+    UR_REQUIRE(ws_bytes >= ur_convT2x2_wgrad_workspace(d), "convT2x2_wgrad: workspace too small");
+    WgradParams p{};
+    p.u = dy; p.dv = x; p.ws = (float*)workspace;
+    p.N = d->n; p.H = d->oh; p.W = d->ow; p.I = d->cout; p.OH = d->h; p.OW = d->w; p.O = d->cin;
+    p.kh = 2; p.kw = 2; p.stride = 2; p.pad = 0;
+    p.Kred = 4 * d->cout; p.P = d->n * d->h * d->w;
+    p.u_ld = d->out_ld; p.dv_ld = d->in_ld;
+    UR_DISPATCH_DTYPE(d->dtype, return launch_wgrad<T>(p, dw, (hipStream_t)s));
+}
+
+}  // extern "C"

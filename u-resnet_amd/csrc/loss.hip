@@ -1,0 +1,192 @@
+// Loss reductions and output masks (NHWC logits, classes contiguous per pixel).
+//   cross-entropy with ignore_index: one thread per pixel keeps the <=64-class row in registers
+//   (max, log-sum-exp, NLL), wave64 butterfly + LDS for the (sum, valid-count) pair, one partial
+//   per workgroup, a finalize kernel adds the partials in double in a fixed order.
+//   The backward kernel rebuilds softmax from the saved log-sum-exp and scales by the
+//   device-resident valid count, so no host synchronisation sits between forward and backward.
+#include "ur_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ void block_sum2(float a, float b, float* out2) {
+    __shared__ float sh[2][NT / 64];
+    a = ur_wave_sum(a); b = ur_wave_sum(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < NT / 64; ++i) { s0 += sh[0][i]; s1 += sh[1][i]; }
+        out2[0] = s0; out2[1] = s1;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                    long long rows, int classes, int ld, long long ignore_index,
+                                                    float* __restrict__ lse, float* __restrict__ partial) {
+    float nll = 0.f, cnt = 0.f;
+    for (long long r = blockIdx.x * (long long)NT + threadIdx.x; r < rows; r += (long long)gridDim.x * NT) {
+        const T* row = logits + r * ld;
+        float m = -INFINITY;
+        for (int c = 0; c < classes; ++c) m = fmaxf(m, ur_to_float(row[c]));
+        float s = 0.f;
+        for (int c = 0; c < classes; ++c) s += expf(ur_to_float(row[c]) - m);
+        const float l = m + logf(s);
+        lse[r] = l;
+        const long long t = target[r];
+        if (t != ignore_index && t >= 0 && t < classes) { nll += l - ur_to_float(row[t]); cnt += 1.f; }
+    }
+    block_sum2(nll, cnt, partial + (size_t)blockIdx.x * 2);
+}
+
+// out[0] = sum, out[1] = count, out[2] = sum / count (mean; NaN when count == 0, like PyTorch)
+__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ out,
+                                     double fixed_count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0, c = 0.0;
+    for (int i = 0; i < nparts; ++i) { s += partial[i * 2]; c += partial[i * 2 + 1]; }
+    if (fixed_count > 0.0) c = fixed_count;
+    out[0] = (float)s; out[1] = (float)c; out[2] = (float)(s / c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                    long long rows, int classes, int ld, long long ignore_index,
+                                                    const float* __restrict__ lse, const float* __restrict__ count,
+                                                    const float* __restrict__ gout, T* __restrict__ dlogits, int dld) {
+    const float scale = (gout ? gout[0] : 1.f) / count[0];
+    for (long long r = blockIdx.x * (long long)NT + threadIdx.x; r < rows; r += (long long)gridDim.x * NT) {
+        const T* row = logits + r * ld;
+        T* drow = dlogits + r * dld;
+        const long long t = target[r];
+        const bool valid = t != ignore_index && t >= 0 && t < classes;
+        const float l = lse[r];
+        for (int c = 0; c < classes; ++c) {
+            float g = 0.f;
+            if (valid) g = (expf(ur_to_float(row[c]) - l) - (c == t ? 1.f : 0.f)) * scale;
+            drow[c] = ur_from_float<T>(g);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bce_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                     long long count, float* __restrict__ partial) {
+    float s = 0.f;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < count; i += (long long)gridDim.x * NT) {
+        const float x = ur_to_float(logits[i]), t = target[i];
+        s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    }
+    block_sum2(s, 0.f, partial + (size_t)blockIdx.x * 2);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bce_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                     long long count, const float* __restrict__ gout,
+                                                     T* __restrict__ dlogits) {
+    const float scale = (gout ? gout[0] : 1.f) / (float)count;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < count; i += (long long)gridDim.x * NT) {
+        const float x = ur_to_float(logits[i]);
+        const float sg = 1.f / (1.f + expf(-x));
+        dlogits[i] = ur_from_float<T>((sg - target[i]) * scale);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void argmax_kernel(const T* __restrict__ logits, long long rows, int classes, int ld,
+                                                    int64_t* __restrict__ out) {
+    for (long long r = blockIdx.x * (long long)NT + threadIdx.x; r < rows; r += (long long)gridDim.x * NT) {
+        const T* row = logits + r * ld;
+        float m = ur_to_float(row[0]);
+        int best = 0;
+        for (int c = 1; c < classes; ++c) {
+            const float v = ur_to_float(row[c]);
+            // strict '>' keeps the first maximum; a NaN beats every number and the first NaN wins (torch.argmax)
+            if ((v > m) || (v != v && m == m)) { m = v; best = c; }
+        }
+        out[r] = best;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void sigmoid_mask_kernel(const T* __restrict__ logits, long long count,
+                                                          uint8_t* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < count; i += (long long)gridDim.x * NT) {
+        // evaluates sigmoid in fp32 exactly as written in the reference (tiny positive logits round to 0.5 -> false)
+        const float sg = 1.f / (1.f + expf(-ur_to_float(logits[i])));
+        out[i] = sg > 0.5f ? 1 : 0;
+    }
+}
+
+int loss_blocks(long long n) { return ur_grid_1d(n, NT, 1024); }
+
+}  // namespace
+
+extern "C" {
+
+size_t ur_loss_workspace(long long n) { return (size_t)loss_blocks(n) * 2 * sizeof(float); }
+
+int ur_ce_fwd(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
+              long long ignore_index, float* lse, float* out3, void* workspace, size_t ws_bytes, ur_stream_t s) {
+    UR_REQUIRE(logits && target && lse && out3 && workspace && rows > 0 && classes > 0 && ld >= classes,
+               "ce_fwd: bad arguments");
+    UR_REQUIRE(ws_bytes >= ur_loss_workspace(rows), "ce_fwd: workspace too small");
+    const int grid = loss_blocks(rows);
+    float* partial = (float*)workspace;
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ce_fwd_kernel<T>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)logits,
+                                                target, rows, classes, ld, ignore_index, lse, partial));
+    if (int e = ur_check_launch("ce_fwd")) return e;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, grid, out3, 0.0);
+    return ur_check_launch("ce_finalize");
+}
+
+int ur_ce_bwd(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
+              long long ignore_index, const float* lse, const float* count, const float* gout, void* dlogits, int dld,
+              ur_stream_t s) {
+    UR_REQUIRE(logits && target && lse && count && dlogits && rows > 0 && classes > 0 && ld >= classes && dld >= classes,
+               "ce_bwd: bad arguments");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(loss_blocks(rows)), dim3(NT), 0, (hipStream_t)s,
+                                                (const T*)logits, target, rows, classes, ld, ignore_index, lse, count, gout,
+                                                (T*)dlogits, dld));
+    return ur_check_launch("ce_bwd");
+}
+
+int ur_bce_fwd(const void* logits, int dtype, const float* target, long long count, float* out3, void* workspace,
+               size_t ws_bytes, ur_stream_t s) {
+    UR_REQUIRE(logits && target && out3 && workspace && count > 0, "bce_fwd: bad arguments");
+    UR_REQUIRE(ws_bytes >= ur_loss_workspace(count), "bce_fwd: workspace too small");
+    const int grid = loss_blocks(count);
+    float* partial = (float*)workspace;
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bce_fwd_kernel<T>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)logits,
+                                                target, count, partial));
+    if (int e = ur_check_launch("bce_fwd")) return e;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, grid, out3, (double)count);
+    return ur_check_launch("bce_finalize");
+}
+
+int ur_bce_bwd(const void* logits, int dtype, const float* target, long long count, const float* gout, void* dlogits,
+               ur_stream_t s) {
+    UR_REQUIRE(logits && target && dlogits && count > 0, "bce_bwd: bad arguments");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bce_bwd_kernel<T>), dim3(loss_blocks(count)), dim3(NT), 0, (hipStream_t)s,
+                                                (const T*)logits, target, count, gout, (T*)dlogits));
+    return ur_check_launch("bce_bwd");
+}
+
+int ur_argmax_channels(const void* logits, int dtype, long long rows, int classes, int ld, int64_t* out, ur_stream_t s) {
+    UR_REQUIRE(logits && out && rows > 0 && classes > 0 && ld >= classes, "argmax: bad arguments");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((argmax_kernel<T>), dim3(ur_grid_1d(rows, NT)), dim3(NT), 0, (hipStream_t)s,
+                                                (const T*)logits, rows, classes, ld, out));
+    return ur_check_launch("argmax");
+}
+
+int ur_sigmoid_mask(const void* logits, int dtype, long long count, uint8_t* out, ur_stream_t s) {
+    UR_REQUIRE(logits && out && count > 0, "sigmoid_mask: bad arguments");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sigmoid_mask_kernel<T>), dim3(ur_grid_1d(count, NT)), dim3(NT), 0,
+                                                (hipStream_t)s, (const T*)logits, count, out));
+    return ur_check_launch("sigmoid_mask");
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Multi-tensor optimiser steps: one launch updates every parameter tensor of the model.
+// blockIdx.y selects the tensor (pointer table in device memory), blockIdx.x grid-strides over
+// its elements with float4 accesses; fp32 master weights, fp32 moments.
+#include "ur_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__global__ __launch_bounds__(NT) void adam_multi_kernel(const void* const* __restrict__ ptrs,
+                                                        const long long* __restrict__ sizes, float lr, float beta1,
+                                                        float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                        float grad_scale) {
+    const int t = blockIdx.y;
+    float* __restrict__ p = (float*)ptrs[t * 4 + 0];
+    const float* __restrict__ g = (const float*)ptrs[t * 4 + 1];
+    float* __restrict__ m = (float*)ptrs[t * 4 + 2];
+    float* __restrict__ v = (float*)ptrs[t * 4 + 3];
+    const long long n = sizes[t];
+    const float step_size = lr / bc1;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        float gi = g[i] * grad_scale;
+        float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        float mi = m[i] + (gi - m[i]) * (1.f - beta1);          // lerp form used by torch.optim.Adam
+        float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+__global__ __launch_bounds__(NT) void sgd_multi_kernel(const void* const* __restrict__ ptrs,
+                                                       const long long* __restrict__ sizes, float lr, float wd,
+                                                       float grad_scale) {
+    const int t = blockIdx.y;
+    float* __restrict__ p = (float*)ptrs[t * 2 + 0];
+    const float* __restrict__ g = (const float*)ptrs[t * 2 + 1];
+    const long long n = sizes[t];
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        float gi = g[i] * grad_scale;
+        float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        p[i] = pi - lr * gi;
+    }
+}
+
+int blocks_for(long long max_size) {
+    long long b = (max_size + NT * 8 - 1) / (NT * 8);
+    if (b < 1) b = 1;
+    if (b > 128) b = 128;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ur_adam_multi(const void* const* ptrs, const long long* sizes, int ntensors, long long max_size, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, ur_stream_t s) {
+    UR_REQUIRE(ptrs && sizes && ntensors > 0 && ntensors <= 65535 && max_size > 0 && step >= 1, "adam_multi: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks_for(max_size), ntensors), dim3(NT), 0, (hipStream_t)s, ptrs, sizes, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return ur_check_launch("adam_multi");
+}
+
+int ur_sgd_multi(const void* const* ptrs, const long long* sizes, int ntensors, long long max_size, float lr,
+                 float weight_decay, float grad_scale, ur_stream_t s) {
+    UR_REQUIRE(ptrs && sizes && ntensors > 0 && ntensors <= 65535 && max_size > 0, "sgd_multi: bad arguments");
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(blocks_for(max_size), ntensors), dim3(NT), 0, (hipStream_t)s, ptrs, sizes, lr,
+                       weight_decay, grad_scale);
+    return ur_check_launch("sgd_multi");
+}
+
+}  // extern "C"

@@ -1,0 +1,440 @@
+// Bandwidth-bound spatial / layout kernels on NHWC tensors: 2x2 max-pool, bilinear upsample,
+// average pool, channel-window copy (pad + concat), channel shuffle, elementwise add and
+// activations, and the NCHW <-> NHWC boundary transposes.  One pass each, channel-fastest
+// thread mapping so a wave touches contiguous memory, 4-channel (8/16-byte) accesses when the
+// channel counts and pitches allow.
+#include "ur_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+template <typename T, int V> struct Pack {
+    float v[V];
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (V == 4) { float4 f = ur_load4(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+        else v[0] = ur_to_float(*p);
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if constexpr (V == 4) ur_store4(p, make_float4(v[0], v[1], v[2], v[3]));
+        else *p = ur_from_float<T>(v[0]);
+    }
+    __device__ __forceinline__ void fill(float x) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = x;
+    }
+};
+
+#define GRID_STRIDE(i, total) \
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < (total); i += (long long)gridDim.x * NT)
+
+// ------------------------------------------------------------------ max pool 2x2 stride 2
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                         uint8_t* __restrict__ idx, int N, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2, CV = C / V;
+    const long long total = (long long)N * OH * OW * CV;
+    GRID_STRIDE(i, total) {
+        int cv = (int)(i % CV);
+        long long pix = i / CV;
+        int ox = (int)(pix % OW);
+        long long t = pix / OW;
+        int oy = (int)(t % OH), n = (int)(t / OH);
+        const T* base = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * C + cv * V;
+        Pack<T, V> a, b, c, d, o;
+        a.load(base); b.load(base + C); c.load(base + (long long)W * C); d.load(base + (long long)W * C + C);
+        uint8_t sel[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            // first maximum in (ky,kx) scan order wins; NaN propagates like PyTorch (val > max || isnan(val))
+            float m = a.v[k]; int s = 0;
+            if (b.v[k] > m || b.v[k] != b.v[k]) { m = b.v[k]; s = 1; }
+            if (c.v[k] > m || c.v[k] != c.v[k]) { m = c.v[k]; s = 2; }
+            if (d.v[k] > m || d.v[k] != d.v[k]) { m = d.v[k]; s = 3; }
+            o.v[k] = m; sel[k] = (uint8_t)s;
+        }
+        o.store(y + pix * C + cv * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) idx[pix * C + cv * V + k] = sel[k];
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                         T* __restrict__ dx, int N, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2, CV = C / V;
+    const long long total = (long long)N * H * W * CV;
+    GRID_STRIDE(i, total) {
+        int cv = (int)(i % CV);
+        long long pix = i / CV;
+        int ix = (int)(pix % W);
+        long long t = pix / W;
+        int iy = (int)(t % H), n = (int)(t / H);
+        int oy = iy >> 1, ox = ix >> 1;
+        Pack<T, V> o; o.fill(0.f);
+        if (oy < OH && ox < OW) {
+            long long op = (((long long)n * OH + oy) * OW + ox) * C + cv * V;
+            Pack<T, V> g; g.load(dy + op);
+            const int me = (iy & 1) * 2 + (ix & 1);
+#pragma unroll
+            for (int k = 0; k < V; ++k) o.v[k] = idx[op + k] == me ? g.v[k] : 0.f;
+        }
+        o.store(dx + pix * C + cv * V);
+    }
+}
+
+// ------------------------------------------------------------------ bilinear upsample, align_corners = False
+__device__ __forceinline__ void bilin_src(int o, float rscale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float src = rscale * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                          int C, int scale, float rscale) {
+    const int OH = H * scale, OW = W * scale, CV = C / V;
+    const long long total = (long long)N * OH * OW * CV;
+    GRID_STRIDE(i, total) {
+        int cv = (int)(i % CV);
+        long long pix = i / CV;
+        int ox = (int)(pix % OW);
+        long long t = pix / OW;
+        int oy = (int)(t % OH), n = (int)(t / OH);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        bilin_src(oy, rscale, H, y0, y1, ly0, ly1);
+        bilin_src(ox, rscale, W, x0, x1, lx0, lx1);
+        const T* b = x + (long long)n * H * W * C + cv * V;
+        Pack<T, V> v00, v01, v10, v11, o;
+        v00.load(b + ((long long)y0 * W + x0) * C); v01.load(b + ((long long)y0 * W + x1) * C);
+        v10.load(b + ((long long)y1 * W + x0) * C); v11.load(b + ((long long)y1 * W + x1) * C);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            o.v[k] = ly0 * (lx0 * v00.v[k] + lx1 * v01.v[k]) + ly1 * (lx0 * v10.v[k] + lx1 * v11.v[k]);
+        o.store(y + pix * C + cv * V);
+    }
+}
+
+// gather form of the adjoint: each input pixel sums the output pixels that read it (fixed order, no atomics)
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
+                                                          int C, int scale, float rscale) {
+    const int OH = H * scale, OW = W * scale, CV = C / V;
+    const long long total = (long long)N * H * W * CV;
+    GRID_STRIDE(i, total) {
+        int cv = (int)(i % CV);
+        long long pix = i / CV;
+        int ix = (int)(pix % W);
+        long long t = pix / W;
+        int iy = (int)(t % H), n = (int)(t / H);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        const int oy_lo = max(0, scale * (iy - 1)), oy_hi = min(OH, scale * (iy + 2));
+        const int ox_lo = max(0, scale * (ix - 1)), ox_hi = min(OW, scale * (ix + 2));
+        for (int oy = oy_lo; oy < oy_hi; ++oy) {
+            int y0, y1; float l0, l1;
+            bilin_src(oy, rscale, H, y0, y1, l0, l1);
+            float wy = (y0 == iy ? l0 : 0.f) + (y1 == iy ? l1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox < ox_hi; ++ox) {
+                int x0, x1; float m0, m1;
+                bilin_src(ox, rscale, W, x0, x1, m0, m1);
+                float wx = (x0 == ix ? m0 : 0.f) + (x1 == ix ? m1 : 0.f);
+                if (wx == 0.f) continue;
+                Pack<T, V> g; g.load(dy + (((long long)n * OH + oy) * OW + ox) * C + cv * V);
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc[k] += wy * wx * g.v[k];
+            }
+        }
+        Pack<T, V> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.v[k] = acc[k];
+        o.store(dx + pix * C + cv * V);
+    }
+}
+
+// ------------------------------------------------------------------ average pool k x k stride k (floor)
+template <typename T>
+__global__ __launch_bounds__(NT) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                         int C, int k) {
+    const int OH = H / k, OW = W / k;
+    const long long total = (long long)N * OH * OW * C;
+    const float inv = 1.f / (float)(k * k);
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        long long pix = i / C;
+        int ox = (int)(pix % OW);
+        long long t = pix / OW;
+        int oy = (int)(t % OH), n = (int)(t / OH);
+        float s = 0.f;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx)
+                s += ur_to_float(x[(((long long)n * H + oy * k + dy) * W + ox * k + dx) * C + c]);
+        y[i] = ur_from_float<T>(s * inv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
+                                                         int C, int k) {
+    const int OH = H / k, OW = W / k;
+    const long long total = (long long)N * H * W * C;
+    const float inv = 1.f / (float)(k * k);
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        long long pix = i / C;
+        int ix = (int)(pix % W);
+        long long t = pix / W;
+        int iy = (int)(t % H), n = (int)(t / H);
+        int oy = iy / k, ox = ix / k;
+        float v = 0.f;
+        if (oy < OH && ox < OW) v = ur_to_float(dy[(((long long)n * OH + oy) * OW + ox) * C + c]) * inv;
+        dx[i] = ur_from_float<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------ channel-window copy with spatial pad / crop
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void copy_channels_kernel(const T* __restrict__ src, int src_ld, int sh, int sw,
+                                                           T* __restrict__ dst, int dst_ld, int dh, int dw, int pad_t,
+                                                           int pad_l, int N, int C) {
+    const int CV = C / V;
+    const long long total = (long long)N * dh * dw * CV;
+    GRID_STRIDE(i, total) {
+        int cv = (int)(i % CV);
+        long long pix = i / CV;
+        int x = (int)(pix % dw);
+        long long t = pix / dw;
+        int y = (int)(t % dh), n = (int)(t / dh);
+        int sy = y - pad_t, sx = x - pad_l;
+        Pack<T, V> o; o.fill(0.f);
+        if ((unsigned)sy < (unsigned)sh && (unsigned)sx < (unsigned)sw)
+            o.load(src + (((long long)n * sh + sy) * sw + sx) * src_ld + cv * V);
+        o.store(dst + pix * dst_ld + cv * V);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void channel_shuffle_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows,
+                                                             int C, int groups) {
+    const int cpg = C / groups;
+    const long long total = rows * C;
+    GRID_STRIDE(i, total) {
+        int co = (int)(i % C);
+        long long r = i / C;
+        int j = co / groups, g = co - j * groups;      // out channel j*groups + g  <-  in channel g*cpg + j
+        y[i] = x[r * C + g * cpg + j];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void add_inplace_kernel(T* __restrict__ a, const T* __restrict__ b, long long count) {
+    const long long n4 = count / 4;
+    GRID_STRIDE(i, n4) {
+        float4 u = ur_load4(a + i * 4), v = ur_load4(b + i * 4);
+        ur_store4(a + i * 4, make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        long long i = n4 * 4 + threadIdx.x;
+        a[i] = ur_from_float<T>(ur_to_float(a[i]) + ur_to_float(b[i]));
+    }
+}
+
+// ------------------------------------------------------------------ activations (S/C:17-34)
+__device__ __forceinline__ float act_apply(float x, int act, float slope) {
+    switch (act) {
+    case UR_ACT_RELU: return fmaxf(x, 0.f);
+    case UR_ACT_RELU6: return fminf(fmaxf(x, 0.f), 6.f);
+    case UR_ACT_LEAKYRELU: return x > 0.f ? x : x * slope;
+    case UR_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case UR_ACT_HSWISH: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
+    return x;
+}
+__device__ __forceinline__ float act_grad(float x, int act, float slope) {
+    switch (act) {
+    case UR_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case UR_ACT_RELU6: return (x > 0.f && x < 6.f) ? 1.f : 0.f;
+    case UR_ACT_LEAKYRELU: return x > 0.f ? 1.f : slope;
+    case UR_ACT_GELU: {
+        float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+        float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+        return cdf + x * pdf;
+    }
+    case UR_ACT_HSWISH: return x < -3.f ? 0.f : (x <= 3.f ? (2.f * x + 3.f) * (1.f / 6.f) : 1.f);
+    }
+    return 1.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long count, int act,
+                                                     float slope) {
+    GRID_STRIDE(i, count) y[i] = ur_from_float<T>(act_apply(ur_to_float(x[i]), act, slope));
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
+                                                     long long count, int act, float slope) {
+    GRID_STRIDE(i, count) dx[i] = ur_from_float<T>(ur_to_float(dy[i]) * act_grad(ur_to_float(x[i]), act, slope));
+}
+
+// ------------------------------------------------------------------ [B][R][S] -> [B][S][R] with dtype conversion
+template <typename TS, typename TD>
+__global__ void transpose_cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int R, int S) {
+    __shared__ float tile[32][33];
+    const long long b = blockIdx.y;
+    const int tiles_s = (S + 31) / 32;
+    const int r0 = (blockIdx.x / tiles_s) * 32, s0 = (blockIdx.x % tiles_s) * 32;
+    const TS* sp = src + b * (long long)R * S;
+    TD* dp = dst + b * (long long)R * S;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int r = r0 + j, s = s0 + threadIdx.x;
+        if (r < R && s < S) tile[j][threadIdx.x] = ur_to_float(sp[(long long)r * S + s]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int s = s0 + j, r = r0 + threadIdx.x;
+        if (r < R && s < S) dp[(long long)s * R + r] = ur_from_float<TD>(tile[threadIdx.x][j]);
+    }
+}
+
+template <typename TS, typename TD>
+int launch_transpose(const void* src, void* dst, int B, int R, int S, hipStream_t st) {
+    const long long tiles = (long long)ur_cdiv(S, 32) * ur_cdiv(R, 32);
+    if (tiles >= (1LL << 31) || B > 65535) { ur_set_error("transpose: dimension too large"); return UR_ERR_INVALID; }
+    dim3 grid((unsigned)tiles, B, 1);
+    hipLaunchKernelGGL((transpose_cast_kernel<TS, TD>), grid, dim3(32, 8), 0, st, (const TS*)src, (TD*)dst, R, S);
+    return ur_check_launch("transpose_cast");
+}
+
+int transpose_dispatch(const void* src, int sdt, void* dst, int ddt, int B, int R, int S, hipStream_t st) {
+    if (sdt == UR_F32 && ddt == UR_F32) return launch_transpose<float, float>(src, dst, B, R, S, st);
+    if (sdt == UR_F32 && ddt == UR_BF16) return launch_transpose<float, bf16_t>(src, dst, B, R, S, st);
+    if (sdt == UR_BF16 && ddt == UR_F32) return launch_transpose<bf16_t, float>(src, dst, B, R, S, st);
+    if (sdt == UR_BF16 && ddt == UR_BF16) return launch_transpose<bf16_t, bf16_t>(src, dst, B, R, S, st);
+    ur_set_error("transpose: unsupported dtypes %d -> %d", sdt, ddt);
+    return UR_ERR_INVALID;
+}
+
+bool al(const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; }
+int esize(int dtype) { return dtype == UR_BF16 ? 2 : 4; }
+
+}  // namespace
+
+#define SPATIAL_LAUNCH(kernel, total, ...)                                                                     \
+    UR_DISPATCH_DTYPE(dtype, {                                                                                 \
+        if (vec) hipLaunchKernelGGL((kernel<T, 4>), dim3(ur_grid_1d((total) / 4, NT)), dim3(NT), 0, (hipStream_t)s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kernel<T, 1>), dim3(ur_grid_1d((total), NT)), dim3(NT), 0, (hipStream_t)s, __VA_ARGS__);        \
+    })
+
+extern "C" {
+
+int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, int h, int w, int c, ur_stream_t s) {
+    UR_REQUIRE(x && y && idx && n > 0 && h >= 2 && w >= 2 && c > 0, "maxpool_fwd: bad arguments");
+    const bool vec = c % 4 == 0 && al(x, 4 * esize(dtype)) && al(y, 4 * esize(dtype));
+    const long long total = (long long)n * (h / 2) * (w / 2) * c;
+    SPATIAL_LAUNCH(maxpool_fwd_kernel, total, (const T*)x, (T*)y, idx, n, h, w, c);
+    return ur_check_launch("maxpool_fwd");
+}
+
+int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int n, int h, int w, int c, ur_stream_t s) {
+    UR_REQUIRE(dy && dx && idx && n > 0 && h >= 2 && w >= 2 && c > 0, "maxpool_bwd: bad arguments");
+    const bool vec = c % 4 == 0 && al(dy, 4 * esize(dtype)) && al(dx, 4 * esize(dtype));
+    const long long total = (long long)n * h * w * c;
+    SPATIAL_LAUNCH(maxpool_bwd_kernel, total, (const T*)dy, idx, (T*)dx, n, h, w, c);
+    return ur_check_launch("maxpool_bwd");
+}
+
+int ur_upsample_bilinear_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c, int scale, ur_stream_t s) {
+    UR_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && scale >= 1, "upsample_fwd: bad arguments");
+    const bool vec = c % 4 == 0 && al(x, 4 * esize(dtype)) && al(y, 4 * esize(dtype));
+    const long long total = (long long)n * h * scale * w * scale * c;
+    const float rscale = (float)(1.0 / (double)scale);
+    SPATIAL_LAUNCH(upsample_fwd_kernel, total, (const T*)x, (T*)y, n, h, w, c, scale, rscale);
+    return ur_check_launch("upsample_fwd");
+}
+
+int ur_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int n, int h, int w, int c, int scale, ur_stream_t s) {
+    UR_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && scale >= 1, "upsample_bwd: bad arguments");
+    const bool vec = c % 4 == 0 && al(dy, 4 * esize(dtype)) && al(dx, 4 * esize(dtype));
+    const long long total = (long long)n * h * w * c;
+    const float rscale = (float)(1.0 / (double)scale);
+    SPATIAL_LAUNCH(upsample_bwd_kernel, total, (const T*)dy, (T*)dx, n, h, w, c, scale, rscale);
+    return ur_check_launch("upsample_bwd");
+}
+
+int ur_avgpool_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c, int k, ur_stream_t s) {
+    UR_REQUIRE(x && y && n > 0 && k > 0 && h >= k && w >= k && c > 0, "avgpool_fwd: bad arguments");
+    const long long total = (long long)n * (h / k) * (w / k) * c;
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0,
+                                                (hipStream_t)s, (const T*)x, (T*)y, n, h, w, c, k));
+    return ur_check_launch("avgpool_fwd");
+}
+
+int ur_avgpool_bwd(const void* dy, void* dx, int dtype, int n, int h, int w, int c, int k, ur_stream_t s) {
+    UR_REQUIRE(dy && dx && n > 0 && k > 0 && h >= k && w >= k && c > 0, "avgpool_bwd: bad arguments");
+    const long long total = (long long)n * h * w * c;
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0,
+                                                (hipStream_t)s, (const T*)dy, (T*)dx, n, h, w, c, k));
+    return ur_check_launch("avgpool_bwd");
+}
+
+int ur_copy_channels(const void* src, int src_ld, int src_coff, int sh, int sw, void* dst, int dst_ld, int dst_coff,
+                     int dh, int dw, int pad_t, int pad_l, int n, int c, int dtype, ur_stream_t s) {
+    UR_REQUIRE(src && dst && n > 0 && c > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0, "copy_channels: bad arguments");
+    UR_REQUIRE(src_coff >= 0 && dst_coff >= 0 && src_coff + c <= src_ld && dst_coff + c <= dst_ld,
+               "copy_channels: channel window outside the buffer pitch");
+    const int es = esize(dtype);
+    const char* sp = (const char*)src + (size_t)src_coff * es;
+    char* dp = (char*)dst + (size_t)dst_coff * es;
+    const bool vec = c % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0 && al(sp, 4 * es) && al(dp, 4 * es);
+    const long long total = (long long)n * dh * dw * c;
+    SPATIAL_LAUNCH(copy_channels_kernel, total, (const T*)sp, src_ld, sh, sw, (T*)dp, dst_ld, dh, dw, pad_t, pad_l, n, c);
+    return ur_check_launch("copy_channels");
+}
+
+int ur_channel_shuffle(const void* x, void* y, int dtype, long long rows, int c, int groups, ur_stream_t s) {
+    UR_REQUIRE(x && y && rows > 0 && c > 0 && groups > 0 && c % groups == 0, "channel_shuffle: bad arguments");
+    const long long total = rows * c;
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_shuffle_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0,
+                                                (hipStream_t)s, (const T*)x, (T*)y, rows, c, groups));
+    return ur_check_launch("channel_shuffle");
+}
+
+int ur_add_inplace(void* a, const void* b, int dtype, long long count, ur_stream_t s) {
+    UR_REQUIRE(a && b && count > 0, "add_inplace: bad arguments");
+    UR_REQUIRE(al(a, 4 * esize(dtype)) && al(b, 4 * esize(dtype)), "add_inplace: buffers must be 4-element aligned");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((add_inplace_kernel<T>), dim3(ur_grid_1d(count / 4 + 1, NT)), dim3(NT), 0,
+                                                (hipStream_t)s, (T*)a, (const T*)b, count));
+    return ur_check_launch("add_inplace");
+}
+
+int ur_act_fwd(const void* x, void* y, int dtype, long long count, int act, float slope, ur_stream_t s) {
+    UR_REQUIRE(x && y && count > 0 && act >= UR_ACT_NONE && act <= UR_ACT_HSWISH, "act_fwd: bad arguments");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((act_fwd_kernel<T>), dim3(ur_grid_1d(count, NT)), dim3(NT), 0,
+                                                (hipStream_t)s, (const T*)x, (T*)y, count, act, slope));
+    return ur_check_launch("act_fwd");
+}
+
+int ur_act_bwd(const void* dy, const void* x, void* dx, int dtype, long long count, int act, float slope, ur_stream_t s) {
+    UR_REQUIRE(dy && x && dx && count > 0 && act >= UR_ACT_NONE && act <= UR_ACT_HSWISH, "act_bwd: bad arguments");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(ur_grid_1d(count, NT)), dim3(NT), 0,
+                                                (hipStream_t)s, (const T*)dy, (const T*)x, (T*)dx, count, act, slope));
+    return ur_check_launch("act_bwd");
+}
+
+int ur_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int h, int w, ur_stream_t s) {
+    UR_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc: bad arguments");
+    return transpose_dispatch(src, src_dtype, dst, dst_dtype, n, c, h * w, (hipStream_t)s);
+}
+
+int ur_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int h, int w, ur_stream_t s) {
+    UR_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "nhwc_to_nchw: bad arguments");
+    return transpose_dispatch(src, src_dtype, dst, dst_dtype, n, h * w, c, (hipStream_t)s);
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Shared device/host helpers for the U-ResNet HIP kernels (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/uresnet_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// ---- host-side error plumbing (never throws across the C ABI) -----------------------------
+void ur_set_error(const char* fmt, ...);
+int ur_check_launch(const char* what);
+
+#define UR_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            ur_set_error(__VA_ARGS__);        \
+            return UR_ERR_INVALID;            \
+        }                                     \
+    } while (0)
+
+static inline int ur_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int ur_grid_1d(long long work_items, int block, int cap = 256 * 16) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---- element access templated on the storage type -----------------------------------------
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int dtype = UR_F32; };
+template <> struct ElemTraits<bf16_t> { static constexpr int dtype = UR_BF16; };
+
+__device__ __forceinline__ float ur_to_float(float v) { return v; }
+__device__ __forceinline__ float ur_to_float(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T ur_from_float(float v);
+template <> __device__ __forceinline__ float ur_from_float<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t ur_from_float<bf16_t>(float v) { return (bf16_t)v; }
+
+// 4 consecutive elements -> float4 (pointer must be 4-element aligned)
+__device__ __forceinline__ float4 ur_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ur_load4(const bf16_t* p) {
+    bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void ur_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void ur_store4(bf16_t* p, float4 v) {
+    bf16x4_t o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+    *reinterpret_cast<bf16x4_t*>(p) = o;
+}
+
+// wave64 butterfly sum
+__device__ __forceinline__ float ur_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#define UR_DISPATCH_DTYPE(dtype, ...)                                  \
+    do {                                                               \
+        if ((dtype) == UR_F32) { typedef float T; __VA_ARGS__; }       \
+        else if ((dtype) == UR_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+        else { ur_set_error("unsupported dtype %d", (int)(dtype)); return UR_ERR_INVALID; } \
+    } while (0)

@@ -1,0 +1,136 @@
+"""Data parallelism: one process per GPU, gradient buckets all-reduced over RCCL (xGMI) while the
+backward pass is still producing the remaining weight gradients.
+
+Replaces the reference's single-process `torch.nn.DataParallel` wrap
+(Segmentation/Cityscapes/train_UResNetAblitionStudy.py:197-198) and keeps its semantics:
+  * every replica normalises with its OWN batch statistics (no SyncBN), and
+  * the loss is the mean over the valid pixels of the GLOBAL batch (DataParallel computes the
+    loss on gathered outputs): `count_hook` sums the per-rank valid-pixel counts (one scalar
+    all-reduce) before the backward pass scales d(logits), and gradients are then SUMMED.
+Parameters that receive no gradient (the reference's classification nets construct unused
+layers) keep `grad is None` on every rank.
+
+Works with any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    def __init__(self, params, device):
+        self.params = params
+        self.offsets = []
+        n = 0
+        for p in params:
+            self.offsets.append(n)
+            n += (p.numel() + 63) // 64 * 64                 # keep every slice 256-byte aligned
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.pending = len(params)
+        self.work = None
+        self.had_grad = [False] * len(params)
+
+    def view(self, i):
+        p = self.params[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
+
+
+class DataParallel:
+    """Bucketed, overlapped gradient all-reduce for a replicated model.
+
+    usage per step:
+        out = ddp.module(x); loss = compute_loss(out, y, ddp.count_hook)
+        optimizer.zero_grad(); loss.backward(); ddp.finish(); optimizer.step()
+    """
+
+    def __init__(self, module, process_group=None, bucket_mb=32.0, average=False, broadcast=True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (launch one process per GPU)")
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.average = average                  # True: mean of per-rank gradients; False: sum
+        params = [p for p in module.parameters() if p.requires_grad]
+        if broadcast:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=process_group)
+        # Buckets follow REVERSE registration order, which is close to the order backward
+        # produces gradients in (head first, stem last); readiness is tracked per parameter.
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(params):
+            if cur and (size + p.numel() > cap or cur[0].device != p.device):
+                self.buckets.append(_Bucket(cur, cur[0].device))
+                cur, size = [], 0
+            cur.append(p)
+            size += p.numel()
+        if cur:
+            self.buckets.append(_Bucket(cur, cur[0].device))
+        self._where = {}
+        for b in self.buckets:
+            for i, p in enumerate(b.params):
+                self._where[p] = (b, i)
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        self._armed = True
+
+    # -- loss normalisation over the global batch ------------------------------------------
+    def count_hook(self, out3):
+        """out3 = [local NLL sum, local valid count, local mean] -> global valid count (1-element tensor)."""
+        count = out3[1:2].clone()
+        dist.all_reduce(count, op=dist.ReduceOp.SUM, group=self.group)
+        return count
+
+    # -- gradient buckets ---------------------------------------------------------------------
+    def _launch(self, b):
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b, i = self._where[p]
+        b.view(i).copy_(p.grad)
+        b.had_grad[i] = True
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Wait for every bucket; parameters then read their reduced gradient straight from the bucket."""
+        for b in self.buckets:
+            if b.work is None:                   # some parameters never produced a gradient
+                if not any(b.had_grad):
+                    self._reset(b)
+                    continue
+                for i, had in enumerate(b.had_grad):
+                    if not had:
+                        b.view(i).zero_()
+                self._launch(b)
+        for b in self.buckets:
+            if b.work is None:
+                continue
+            b.work.wait()
+            if self.average:
+                b.flat.mul_(1.0 / self.world)
+            self._armed = False
+            for i, p in enumerate(b.params):
+                if b.had_grad[i]:
+                    p.grad = b.view(i)
+            self._armed = True
+            self._reset(b)
+
+    @staticmethod
+    def _reset(b):
+        b.pending = len(b.params)
+        b.work = None
+        b.had_grad = [False] * len(b.params)
+
+    def __call__(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def shard_batch(batch, rank, world):
+    """Rank r takes samples [r*B/world, (r+1)*B/world) of a global batch (dim 0)."""
+    b = batch.shape[0]
+    if b % world != 0:
+        raise ValueError("global batch %d is not divisible by world size %d" % (b, world))
+    per = b // world
+    return batch[rank * per:(rank + 1) * per]

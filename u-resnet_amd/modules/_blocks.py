@@ -1,0 +1,291 @@
+"""U-ResNet building blocks (ResBlock, UBlock halves, EUCB / EUCB*, heads) on the HIP operators.
+
+Constructor signatures, sub-module names and state_dict keys follow the reference files
+(S/C = Segmentation/Cityscapes/modules/U_ResNet.py, C/C = Classification/modules/U_ResNet_CIFAR.py).
+Containers run a fused schedule (conv with BN statistics in its epilogue, then one
+normalise+residual+ReLU pass); when a forward hook is registered on any child they run child by
+child instead, so feature-map hooks see every intermediate tensor.
+"""
+from .. import _lib, ops
+from .. import nn as hnn
+from ..nn import act_dtype, conv_bn_act, has_hooks
+
+_ACT_CODES = {hnn.ReLU: _lib.ACT_RELU}
+
+
+def channel_shuffle(x, groups):
+    """S/C:6-15 (identity, returned as is, when groups == C)."""
+    return ops.channel_shuffle(ops.as_activation(x, act_dtype(x)), groups)
+
+
+def act_layer(act, inplace=False, neg_slope=0.2, n_prelu=1):
+    """S/C:17-34."""
+    act = act.lower()
+    if act == 'relu':
+        return hnn.ReLU(inplace)
+    if act == 'relu6':
+        return hnn.ReLU6(inplace)
+    if act == 'leakyrelu':
+        return hnn.LeakyReLU(neg_slope, inplace)
+    if act == 'gelu':
+        return hnn.GELU()
+    if act == 'hswish':
+        return hnn.Hardswish(inplace)
+    if act == 'prelu':
+        raise NotImplementedError("activation layer [prelu] has no HIP kernel (U-ResNet never selects it)")
+    raise NotImplementedError('activation layer [%s] is not found' % act)
+
+
+def _cba(seq, x, i):
+    """Run seq[i] (conv), seq[i+1] (BN), seq[i+2] (activation) fused when the activation is ReLU."""
+    conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
+    if type(act) in _ACT_CODES:
+        return conv_bn_act(x, conv, bn, _ACT_CODES[type(act)])
+    return act(conv_bn_act(x, conv, bn, _lib.ACT_NONE))
+
+
+class EUCB(hnn.Module):
+    """S/C:36-57: bilinear up -> depthwise 3x3 -> BN -> act -> shuffle(groups=C) -> 1x1 conv."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, activation='relu', scale_factor=2):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.up_dwc = hnn.Sequential(
+            hnn.Upsample(scale_factor=scale_factor, mode="bilinear"),
+            hnn.Conv2d(in_channels, in_channels, kernel_size=kernel_size, stride=stride, padding=kernel_size // 2,
+                       groups=in_channels, bias=False),
+            hnn.BatchNorm2d(in_channels),
+            act_layer(activation, inplace=True))
+        self.pwc = hnn.Sequential(hnn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0, bias=True))
+
+    def forward(self, x):
+        x = ops.as_activation(x, act_dtype(x))
+        if has_hooks(self.up_dwc, *self.up_dwc, self.pwc, *self.pwc):
+            x = self.up_dwc(x)
+        else:
+            x = _cba(self.up_dwc, self.up_dwc[0](x), 1)
+        x = channel_shuffle(x, self.in_channels)
+        return self.pwc(x)
+
+
+class EUCB2(hnn.Module):
+    """EUCB*: grouped 3x3 convs (groups = C/4).  stages=2: S/C:59-87; stages=3: C/C:64-100."""
+    stages = 2
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, activation='relu', scale_factor=2):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+
+        def stage():
+            return [hnn.Conv2d(in_channels, in_channels, kernel_size=kernel_size, stride=stride,
+                               padding=kernel_size // 2, groups=in_channels // 4, bias=False),
+                    hnn.BatchNorm2d(in_channels), act_layer(activation, inplace=True)]
+
+        self.up_dwc1 = hnn.Sequential(hnn.Upsample(scale_factor=scale_factor, mode="bilinear"), *stage())
+        self.up_dwc2 = hnn.Sequential(*stage())
+        if self.stages == 3:
+            self.up_dwc3 = hnn.Sequential(*stage())
+        self.pwc = hnn.Sequential(hnn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0, bias=True))
+
+    def _seqs(self):
+        return [self.up_dwc1, self.up_dwc2] + ([self.up_dwc3] if self.stages == 3 else [])
+
+    def forward(self, x):
+        x = ops.as_activation(x, act_dtype(x))
+        hooked = has_hooks(self.pwc, *self.pwc, *[m for s in self._seqs() for m in (s, *s)])
+        for k, seq in enumerate(self._seqs()):
+            if k > 0:
+                x = channel_shuffle(x, self.in_channels)
+            if hooked:
+                x = seq(x)
+            elif k == 0:
+                x = _cba(seq, seq[0](x), 1)
+            else:
+                x = _cba(seq, x, 0)
+        return self.pwc(x)
+
+
+class EUCB2x3(EUCB2):
+    stages = 3
+
+
+class DoubleConv(hnn.Sequential):
+    """S/C:89-100: (conv3x3 -> BN -> ReLU) x 2."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        if mid_channels is None:
+            mid_channels = out_channels
+        super().__init__(
+            hnn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False),
+            hnn.BatchNorm2d(mid_channels),
+            hnn.ReLU(inplace=True),
+            hnn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            hnn.BatchNorm2d(out_channels),
+            hnn.ReLU(inplace=True))
+
+    def forward(self, x):
+        x = ops.as_activation(x, act_dtype(x))
+        if has_hooks(*self):
+            return super().forward(x)
+        return _cba(self, _cba(self, x, 0), 3)
+
+
+class Down(hnn.Sequential):
+    """S/C:102-107: MaxPool2d(2,2) -> DoubleConv."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(hnn.MaxPool2d(2, stride=2), DoubleConv(in_channels, out_channels))
+
+
+class Up(hnn.Module):
+    """S/C:109-126: ConvTranspose2d(2,2) -> pad to the skip's size -> cat([skip, up]) -> DoubleConv."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.up = hnn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+        self.conv = DoubleConv(in_channels, out_channels)
+
+    def forward(self, x1, x2):
+        x1 = self.up(x1)
+        x2 = ops.as_activation(x2, x1.dtype)
+        return self.conv(ops.cat_pad(x2, x1))
+
+
+class OutConv(hnn.Sequential):
+    """Segmentation head S/C:127-133: BN -> ReLU -> 1x1 conv (+bias)."""
+
+    def __init__(self, in_channels, num_classes):
+        super().__init__(hnn.BatchNorm2d(in_channels), hnn.ReLU(), hnn.Conv2d(in_channels, num_classes, kernel_size=1))
+
+    def forward(self, x):
+        x = ops.as_activation(x, act_dtype(x))
+        if has_hooks(*self):
+            return super().forward(x)
+        return self[2](ops.bn_act(x, self[0], act=_lib.ACT_RELU))
+
+
+class OutConvPlain(hnn.Sequential):
+    """Classification head C/C:148-152: a bare 1x1 conv (+bias)."""
+
+    def __init__(self, in_channels, num_classes):
+        super().__init__(hnn.Conv2d(in_channels, num_classes, kernel_size=1))
+
+
+class BasicBlock(hnn.Module):
+    """ResBlock S/C:135-160: relu(BN(conv(relu(BN(conv(x))))) + shortcut(x))."""
+
+    def __init__(self, inchannel, outchannel, stride=1):
+        super().__init__()
+        self.name = "Basic-Block-ResNet"
+        self.left = hnn.Sequential(
+            hnn.Conv2d(inchannel, outchannel, kernel_size=3, stride=stride, padding=1, bias=False),
+            hnn.BatchNorm2d(outchannel),
+            hnn.ReLU(inplace=True),
+            hnn.Conv2d(outchannel, outchannel, kernel_size=3, stride=1, padding=1, bias=False),
+            hnn.BatchNorm2d(outchannel))
+        self.shortcut = hnn.Sequential()
+        if stride != 1 or inchannel != outchannel:
+            self.shortcut = hnn.Sequential(
+                hnn.Conv2d(inchannel, outchannel, kernel_size=1, stride=stride, bias=False),
+                hnn.BatchNorm2d(outchannel))
+
+    def forward(self, x):
+        x = ops.as_activation(x, act_dtype(x))
+        if has_hooks(self.left, *self.left, self.shortcut, *self.shortcut):
+            out = ops.add(self.left(x), self.shortcut(x))
+            return ops.activation(out, _lib.ACT_RELU)
+        out = _cba(self.left, x, 0)
+        sc = x if len(self.shortcut) == 0 else conv_bn_act(x, self.shortcut[0], self.shortcut[1], _lib.ACT_NONE)
+        # second conv's BN, the residual add and the final ReLU are one pass
+        return conv_bn_act(out, self.left[3], self.left[4], _lib.ACT_RELU, residual=sc)
+
+
+class Bottleneck(hnn.Module):
+    """S/C:162-188 (defined by the reference, not used by any U-ResNet variant); runs layer by layer."""
+
+    def __init__(self, inchannel, outchannel, stride=1):
+        super().__init__()
+        self.name = 'Bottleneck'
+        mid = int(outchannel / 4)
+        self.left = hnn.Sequential(
+            hnn.Conv2d(inchannel, mid, kernel_size=1, stride=stride, padding=0, bias=False), hnn.BatchNorm2d(mid),
+            hnn.ReLU(inplace=True),
+            hnn.Conv2d(mid, mid, kernel_size=3, stride=1, padding=1, bias=False), hnn.BatchNorm2d(mid),
+            hnn.ReLU(inplace=True),
+            hnn.Conv2d(mid, outchannel, kernel_size=1, stride=1, padding=0, bias=False), hnn.BatchNorm2d(outchannel))
+        self.shortcut = hnn.Sequential()
+        if stride != 1 or inchannel != outchannel:
+            self.shortcut = hnn.Sequential(
+                hnn.Conv2d(inchannel, outchannel, kernel_size=1, stride=stride, bias=False),
+                hnn.BatchNorm2d(outchannel))
+
+    def forward(self, x):
+        x = ops.as_activation(x, act_dtype(x))
+        return ops.activation(ops.add(self.left(x), self.shortcut(x)), _lib.ACT_RELU)
+
+
+def stem(in_channels, selected_upsampling=False):
+    """conv1: [SU = bilinear x2 (C/C:302-307)] -> 7x7 s2 conv -> BN -> ReLU (S/C:229-233)."""
+    layers = [hnn.Upsample(scale_factor=2, mode='bilinear')] if selected_upsampling else []
+    layers += [hnn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False), hnn.BatchNorm2d(64),
+               hnn.ReLU()]
+    return hnn.Sequential(*layers)
+
+
+def run_stem(seq, x):
+    if has_hooks(seq, *seq):
+        return seq(x)
+    if len(seq) == 4:
+        x = seq[0](x)
+        return _cba(seq, x, 1)
+    return _cba(seq, x, 0)
+
+
+class ResTrunk(hnn.Module):
+    """make_layer bookkeeping (S/C:252-258) shared by the top-level networks."""
+
+    def make_layer(self, block, channels, num_blocks, stride):
+        strides = [stride] + [1] * (num_blocks - 1)
+        layers = []
+        for stride in strides:
+            layers.append(block(self.inchannel, channels, stride))
+            self.inchannel = channels
+        return hnn.Sequential(*layers)
+
+    def _build_res(self, block, widths, strides):
+        self.inchannel = 64
+        for i, (c, s) in enumerate(zip(widths, strides), 1):
+            setattr(self, 'ResLayer%d' % i, self.make_layer(block, c, 2, s))
+
+    def _res_forward(self, x):
+        out = run_stem(self.conv1, x)
+        for i in (1, 2, 3, 4):
+            out = getattr(self, 'ResLayer%d' % i)(out)
+        return out
+
+    def set_compute_dtype(self, dtype):
+        import torch
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
+
+
+def add_unet_branch(m, in_channels, base_c, levels=4):
+    m.in_conv = DoubleConv(in_channels, base_c)
+    for i in range(levels):
+        setattr(m, 'down%d' % (i + 1), Down(base_c << i, base_c << (i + 1)))
+
+
+def unet_branch_forward(m, x):
+    x1 = m.in_conv(x)
+    x2 = m.down1(x1)
+    x3 = m.down2(x2)
+    x4 = m.down3(x3)
+    x5 = m.down4(x4)
+    u = m.up1(x5, x4)
+    u = m.up2(u, x3)
+    u = m.up3(u, x2)
+    return m.up4(u, x1)

@@ -1,0 +1,665 @@
+"""Autograd operators over the C ABI of liburesnet_hip.so.
+
+Every operator takes / returns torch tensors that are logically NCHW but physically NHWC
+(torch.channels_last), in the model's activation dtype (bf16 or fp32).  torch supplies device
+memory, streams and the autograd tape only: all arithmetic runs in the hand-written HIP
+kernels.  Parameters and their gradients are fp32 in PyTorch's native layouts, so
+state_dicts are interchangeable with the reference's.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import ConvDesc, call, query
+
+CL = torch.channels_last
+_DT = {torch.float32: _lib.UR_F32, torch.bfloat16: _lib.UR_BF16}
+
+_weights_epoch = 0          # bumped whenever this package's optimisers rewrite parameters in place
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("unsupported activation dtype %s (use torch.float32 or torch.bfloat16)" % t.dtype)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise _lib.UResNetHipError("u-resnet_amd operators run on the GPU only (got a %s tensor); "
+                                   "there is no CPU fallback" % t.device)
+
+
+def empty_nhwc(n, c, h, w, dtype, device):
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=CL)
+
+
+def _is_nhwc_dense(x):
+    n, c, h, w = x.shape
+    return x.stride() == (h * w * c, 1, w * c, c) or x.is_contiguous(memory_format=CL)
+
+
+def to_nhwc_raw(x, dtype):
+    """NCHW-contiguous (any supported dtype) -> dense NHWC tensor of `dtype`, via the transpose kernel."""
+    _require_gpu(x)
+    n, c, h, w = x.shape
+    if x.dtype == dtype and _is_nhwc_dense(x):
+        return x
+    if _is_nhwc_dense(x) and not x.is_contiguous():
+        # already channels-last, only the dtype differs: cast the flat buffer (a 1 x numel "transpose")
+        y = empty_nhwc(n, c, h, w, dtype, x.device)
+        call("ur_nchw_to_nhwc", x.data_ptr(), _dt(x), y.data_ptr(), _DT[dtype], 1, 1, 1, x.numel(), _stream())
+        return y
+    if not x.is_contiguous():
+        x = x.contiguous()
+    y = empty_nhwc(n, c, h, w, dtype, x.device)
+    call("ur_nchw_to_nhwc", x.data_ptr(), _dt(x), y.data_ptr(), _DT[dtype], n, c, h, w, _stream())
+    return y
+
+
+def to_nchw_raw(x, dtype):
+    """dense NHWC -> NCHW-contiguous tensor of `dtype`."""
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h, w), dtype=dtype, device=x.device)
+    call("ur_nhwc_to_nchw", x.data_ptr(), _dt(x), y.data_ptr(), _DT[dtype], n, c, h, w, _stream())
+    return y
+
+
+class _ToNHWC(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.in_dtype = x.dtype
+        ctx.in_cl = _is_nhwc_dense(x) and not x.is_contiguous()
+        return to_nhwc_raw(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _g(g)
+        if ctx.in_cl:
+            return to_nhwc_raw(g, ctx.in_dtype), None
+        return to_nchw_raw(g, ctx.in_dtype), None
+
+
+def as_activation(x, dtype):
+    """Model-boundary conversion: any 4-D input -> dense NHWC tensor of the compute dtype."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D NCHW tensor, got shape %s" % (tuple(x.shape),))
+    if x.dtype == dtype and x.is_cuda and _is_nhwc_dense(x):
+        return x
+    return _ToNHWC.apply(x, dtype)
+
+
+def _g(g):
+    """Incoming gradient -> dense NHWC tensor (autograd may hand over NCHW or expanded tensors)."""
+    if _is_nhwc_dense(g):
+        return g
+    return to_nhwc_raw(g.contiguous(), g.dtype)
+
+
+class _ToNCHW(Function):
+    """NHWC activation -> NCHW-contiguous tensor (used where the reference flattens in NCHW order)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype_in = x.dtype
+        return to_nchw_raw(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_nhwc_raw(g.contiguous(), ctx.dtype_in), None
+
+
+def to_nchw(x, dtype=None):
+    return _ToNCHW.apply(x, dtype or x.dtype)
+
+
+# ------------------------------------------------------------------------------ dense convolution
+def _desc(x_shape, cout, kh, kw, stride, pad, dtype, oh=None, ow=None):
+    n, cin, h, w = x_shape
+    d = ConvDesc()
+    d.dtype = _DT[dtype]
+    d.n, d.h, d.w, d.cin = n, h, w, cin
+    d.oh = (h + 2 * pad - kh) // stride + 1 if oh is None else oh
+    d.ow = (w + 2 * pad - kw) // stride + 1 if ow is None else ow
+    d.cout = cout
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    d.in_ld, d.out_ld = cin, cout
+    return d
+
+
+class PackedWeights:
+    """Per-layer cache of the weight matrices the GEMM kernels consume (activation dtype, k-major)."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, weight, d, mode):
+        key = (weight.data_ptr(), weight._version, _weights_epoch, d.dtype, d.cin, d.cout)
+        hit = self._cache.get(mode)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        elems = query("ur_conv2d_packed_elems", C.byref(d), mode)
+        packed = torch.empty(elems, dtype=torch.bfloat16 if d.dtype == _lib.UR_BF16 else torch.float32,
+                             device=weight.device)
+        call("ur_conv2d_pack_weight", weight.data_ptr(), packed.data_ptr(), C.byref(d), mode, _stream())
+        self._cache[mode] = (key, packed)
+        return packed
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _colsum(t2d_ptr, dtype_code, rows, c, ld, device):
+    out = torch.empty(c, dtype=torch.float32, device=device)
+    ws = _workspace(query("ur_colsum_workspace", rows, c), device)
+    call("ur_colsum", t2d_ptr, dtype_code, rows, c, ld, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, packs, stride, pad, want_stats):
+        _require_gpu(x)
+        cout, cin, kh, kw = weight.shape
+        if x.shape[1] != cin:
+            raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], cin))
+        d = _desc(x.shape, cout, kh, kw, stride, pad, x.dtype)
+        if d.oh <= 0 or d.ow <= 0:
+            raise RuntimeError("conv2d: kernel %dx%d does not fit input %dx%d" % (kh, kw, d.h, d.w))
+        wp = packs.get(weight, d, _lib.PACK_FWD)
+        y = empty_nhwc(d.n, cout, d.oh, d.ow, x.dtype, x.device)
+        stats = None
+        if want_stats:
+            rows = query("ur_conv2d_stats_rows", C.byref(d))
+            stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
+        call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
+        ctx.save_for_backward(x, weight)
+        ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, weight = ctx.saved_tensors
+        d = ctx.d
+        dy = _g(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = ctx.packs.get(weight, d, _lib.PACK_DGRAD)
+            dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
+            call("ur_conv2d_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            ws = _workspace(query("ur_conv2d_wgrad_workspace", C.byref(d)), x.device)
+            call("ur_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                 C.byref(d), _stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, d.cout, d.cout, x.device)
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias, packs, stride=1, pad=0, want_stats=False):
+    return _Conv2d.apply(x, weight, bias, packs, stride, pad, want_stats)
+
+
+class _ConvT2x2(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, packs):
+        _require_gpu(x)
+        cin, cout, kh, kw = weight.shape
+        if (kh, kw) != (2, 2) or x.shape[1] != cin:
+            raise RuntimeError("conv_transpose2d: only kernel 2x2 stride 2 is implemented (weight %s, input %s)"
+                               % (tuple(weight.shape), tuple(x.shape)))
+        n, _, h, w = x.shape
+        d = _desc(x.shape, cout, 2, 2, 2, 0, x.dtype, oh=2 * h, ow=2 * w)
+        wp = packs.get(weight, d, _lib.PACK_CONVT_FWD)
+        y = empty_nhwc(n, cout, 2 * h, 2 * w, x.dtype, x.device)
+        call("ur_convT2x2_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), C.byref(d), _stream())
+        ctx.save_for_backward(x, weight)
+        ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        d = ctx.d
+        dy = _g(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = ctx.packs.get(weight, d, _lib.PACK_CONVT_DGRAD)
+            dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
+            call("ur_convT2x2_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            ws = _workspace(query("ur_convT2x2_wgrad_workspace", C.byref(d)), x.device)
+            call("ur_convT2x2_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                 C.byref(d), _stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, d.cout, d.cout, x.device)
+        return dx, dw, db, None
+
+
+def conv_transpose2x2(x, weight, bias, packs):
+    return _ConvT2x2.apply(x, weight, bias, packs)
+
+
+class _GConv3x3(Function):
+    """Grouped 3x3, stride 1, pad 1, with 1 or 4 channels per group."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _require_gpu(x)
+        c, cpg, kh, kw = weight.shape
+        n, cx, h, w = x.shape
+        if (kh, kw) != (3, 3) or cx != c or cpg not in (1, 4):
+            raise RuntimeError("grouped conv: only 3x3 with 1 or 4 channels per group is implemented "
+                               "(weight %s, input %s)" % (tuple(weight.shape), tuple(x.shape)))
+        y = torch.empty_like(x, memory_format=CL)
+        call("ur_gconv3x3_fwd", x.data_ptr(), weight.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, cpg, _stream())
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        c, cpg = weight.shape[0], weight.shape[1]
+        n, _, h, w = x.shape
+        dy = _g(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=CL)
+            call("ur_gconv3x3_dgrad", dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _dt(x), n, h, w, c, cpg,
+                 _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            ws = _workspace(query("ur_gconv3x3_wgrad_workspace", n, h, w, c, cpg), x.device)
+            call("ur_gconv3x3_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), _dt(x),
+                 n, h, w, c, cpg, _stream())
+        return dx, dw
+
+
+def gconv3x3(x, weight):
+    return _GConv3x3.apply(x, weight)
+
+
+# ------------------------------------------------------------------------------ batch norm (+act, +residual)
+class _BNAct(Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, stats, running_mean, running_var, nbt, training, momentum, eps, act):
+        _require_gpu(y)
+        n, c, h, w = y.shape
+        rows = n * h * w
+        dev = y.device
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        if training:
+            if stats is None:
+                nparts = query("ur_bn_stats_rows", rows, c)
+                stats = torch.empty((nparts, c, 2), dtype=torch.float32, device=dev)
+                call("ur_bn_stats", y.data_ptr(), _dt(y), rows, c, stats.data_ptr(), _stream())
+            call("ur_bn_finalize", stats.data_ptr(), stats.shape[0], rows, c, eps, momentum, mean.data_ptr(),
+                 invstd.data_ptr(), _p(running_mean), _p(running_var), _p(nbt), _stream())
+        else:
+            call("ur_bn_eval_prepare", running_mean.data_ptr(), running_var.data_ptr(), c, eps, mean.data_ptr(),
+                 invstd.data_ptr(), _stream())
+        z = torch.empty_like(y, memory_format=CL)
+        call("ur_bn_act_fwd", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+             _p(residual), act, z.data_ptr(), _dt(y), rows, c, _stream())
+        ctx.save_for_backward(y, z if act else None, gamma, mean, invstd)
+        ctx.act, ctx.eval, ctx.has_res = act, not training, residual is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, z, gamma, mean, invstd = ctx.saved_tensors
+        n, c, h, w = y.shape
+        rows = n * h * w
+        dev = y.device
+        dz = _g(dz)
+        nparts = query("ur_bn_stats_rows", rows, c)
+        partial = torch.empty((nparts, c, 2), dtype=torch.float32, device=dev)
+        call("ur_bn_act_bwd_reduce", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(), ctx.act,
+             _dt(y), rows, c, partial.data_ptr(), _stream())
+        sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        call("ur_bn_bwd_finalize", partial.data_ptr(), nparts, c, sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+             _stream())
+        dy = torch.empty_like(y, memory_format=CL)
+        dres = torch.empty_like(y, memory_format=CL) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
+             gamma.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres), _dt(y), rows, c,
+             _stream())
+        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU):
+    """BatchNorm2d module `bn` applied to y, fused with an optional residual add and ReLU."""
+    training = bn.training or bn.running_mean is None
+    if training and bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not implemented")
+    track = training and bn.track_running_stats and bn.running_mean is not None
+    return _BNAct.apply(y, bn.weight, bn.bias, residual, stats if training else None,
+                        bn.running_mean if (track or not training) else None,
+                        bn.running_var if (track or not training) else None,
+                        bn.num_batches_tracked if track else None,
+                        training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, act)
+
+
+# ------------------------------------------------------------------------------ spatial ops
+class _MaxPool2x2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
+        idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
+        call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        dy = _g(dy)
+        dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
+        call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _dt(dy), n, h, w, c, _stream())
+        return dx
+
+
+def maxpool2x2(x):
+    return _MaxPool2x2.apply(x)
+
+
+class _UpsampleBilinear(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        _require_gpu(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h * scale, w * scale, x.dtype, x.device)
+        call("ur_upsample_bilinear_fwd", x.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, scale, _stream())
+        ctx.shape, ctx.scale = (n, c, h, w), scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        dy = _g(dy)
+        dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
+        call("ur_upsample_bilinear_bwd", dy.data_ptr(), dx.data_ptr(), _dt(dy), n, h, w, c, ctx.scale, _stream())
+        return dx, None
+
+
+def upsample_bilinear(x, scale):
+    if int(scale) != scale or scale < 1:
+        raise NotImplementedError("bilinear upsampling is implemented for integer scale factors only (got %r)" % scale)
+    return _UpsampleBilinear.apply(x, int(scale))
+
+
+class _AvgPool(Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        _require_gpu(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h // k, w // k, x.dtype, x.device)
+        call("ur_avgpool_fwd", x.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, k, _stream())
+        ctx.shape, ctx.k = (n, c, h, w), k
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        dy = _g(dy)
+        dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
+        call("ur_avgpool_bwd", dy.data_ptr(), dx.data_ptr(), _dt(dy), n, h, w, c, ctx.k, _stream())
+        return dx, None
+
+
+def avg_pool2d(x, k):
+    return _AvgPool.apply(x, int(k))
+
+
+def _copy_channels(src, src_coff, c, dst, dst_coff, pad_t=0, pad_l=0):
+    n, cs, sh, sw = src.shape
+    _, cd, dh, dw = dst.shape
+    call("ur_copy_channels", src.data_ptr(), cs, src_coff, sh, sw, dst.data_ptr(), cd, dst_coff, dh, dw, pad_t, pad_l,
+         n, c, _dt(src), _stream())
+
+
+class _CatPad(Function):
+    """torch.cat([a, pad(b)], dim=1): b is zero-padded (or cropped) to a's spatial size first (S/C:119-124)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a)
+        n, ca, h, w = a.shape
+        _, cb, hb, wb = b.shape
+        out = empty_nhwc(n, ca + cb, h, w, a.dtype, a.device)
+        pt, pl = (h - hb) // 2, (w - wb) // 2
+        _copy_channels(a, 0, ca, out, 0)
+        _copy_channels(b, 0, cb, out, ca, pt, pl)
+        ctx.meta = (ca, cb, hb, wb, pt, pl)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ca, cb, hb, wb, pt, pl = ctx.meta
+        g = _g(g)
+        n, _, h, w = g.shape
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = empty_nhwc(n, ca, h, w, g.dtype, g.device)
+            _copy_channels(g, 0, ca, ga, 0)
+        if ctx.needs_input_grad[1]:
+            gb = empty_nhwc(n, cb, hb, wb, g.dtype, g.device)
+            _copy_channels(g, ca, cb, gb, 0, -pt, -pl)
+        return ga, gb
+
+
+def cat_pad(a, b):
+    return _CatPad.apply(a, b)
+
+
+class _ChannelShuffle(Function):
+    @staticmethod
+    def forward(ctx, x, groups):
+        n, c, h, w = x.shape
+        y = torch.empty_like(x, memory_format=CL)
+        call("ur_channel_shuffle", x.data_ptr(), y.data_ptr(), _dt(x), n * h * w, c, groups, _stream())
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _g(g)
+        n, c, h, w = g.shape
+        dx = torch.empty_like(g, memory_format=CL)
+        # the inverse permutation of a shuffle with `groups` groups is a shuffle with c/groups groups
+        call("ur_channel_shuffle", g.data_ptr(), dx.data_ptr(), _dt(g), n * h * w, c, c // ctx.groups, _stream())
+        return dx, None
+
+
+def channel_shuffle(x, groups):
+    """Reference S/C:6-15.  groups == C (every call site in U-ResNet) or groups == 1 is the identity
+    permutation: the input is returned unchanged (bit-exact, no copy)."""
+    c = x.shape[1]
+    if c % groups != 0:
+        raise RuntimeError("channel_shuffle: %d channels are not divisible by %d groups" % (c, groups))
+    if groups == c or groups == 1:
+        return x
+    return _ChannelShuffle.apply(x, groups)
+
+
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _require_gpu(x)
+        y = torch.empty_like(x, memory_format=CL) if x.dim() == 4 else torch.empty_like(x)
+        call("ur_act_fwd", x.data_ptr(), y.data_ptr(), _dt(x), x.numel(), act, slope, _stream())
+        ctx.save_for_backward(x)
+        ctx.act, ctx.slope = act, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _g(g) if g.dim() == 4 else g.contiguous()
+        dx = torch.empty_like(g, memory_format=CL) if g.dim() == 4 else torch.empty_like(g)
+        call("ur_act_bwd", g.data_ptr(), x.data_ptr(), dx.data_ptr(), _dt(x), x.numel(), ctx.act, ctx.slope, _stream())
+        return dx, None, None
+
+
+def activation(x, act, slope=0.0):
+    return _Act.apply(x, act, float(slope))
+
+
+class _Add(Function):
+    """out = a + b (residual add outside a fused BN epilogue)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a, memory_format=torch.preserve_format)
+        call("ur_nchw_to_nhwc", a.data_ptr(), _dt(a), out.data_ptr(), _dt(a), 1, 1, 1, a.numel(), _stream())
+        call("ur_add_inplace", out.data_ptr(), b.data_ptr(), _dt(a), a.numel(), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    if a.shape != b.shape or a.stride() != b.stride():
+        raise RuntimeError("add: operands must have identical shape and layout")
+    return _Add.apply(a, b)
+
+
+# ------------------------------------------------------------------------------ losses and masks
+class _CrossEntropy(Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, count_hook):
+        _require_gpu(logits)
+        if logits.dim() == 4:
+            n, c, h, w = logits.shape
+            rows = n * h * w
+            if not _is_nhwc_dense(logits):
+                logits = to_nhwc_raw(logits.contiguous(), logits.dtype)
+        else:
+            rows, c = logits.shape
+            logits = logits.contiguous()
+        target = target.contiguous()
+        if target.dtype != torch.int64:
+            raise TypeError("cross_entropy: target must be int64 (the reference calls targets.long())")
+        if target.numel() != rows:
+            raise RuntimeError("cross_entropy: %d targets for %d logit rows" % (target.numel(), rows))
+        dev = logits.device
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        ws = _workspace(query("ur_loss_workspace", rows), dev)
+        call("ur_ce_fwd", logits.data_ptr(), _dt(logits), target.data_ptr(), rows, c, c, ignore_index, lse.data_ptr(),
+             out3.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        count = out3[1:2]
+        if count_hook is not None:          # data parallel: mean over the GLOBAL number of valid pixels
+            count = count_hook(out3)
+        ctx.save_for_backward(logits, target, lse, count)
+        ctx.meta = (rows, c, ignore_index)
+        return out3[2] if count_hook is None else out3[0] / count[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, lse, count = ctx.saved_tensors
+        rows, c, ignore_index = ctx.meta
+        gout = gout.contiguous().float()
+        dlogits = torch.empty_like(logits, memory_format=torch.preserve_format)
+        call("ur_ce_bwd", logits.data_ptr(), _dt(logits), target.data_ptr(), rows, c, c, ignore_index, lse.data_ptr(),
+             count.data_ptr(), gout.data_ptr(), dlogits.data_ptr(), c, _stream())
+        return dlogits, None, None, None
+
+
+def cross_entropy(logits, target, ignore_index=-100, count_hook=None):
+    return _CrossEntropy.apply(logits, target, ignore_index, count_hook)
+
+
+class _BCEWithLogits(Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        _require_gpu(logits)
+        if logits.dim() == 4 and not _is_nhwc_dense(logits):
+            logits = to_nhwc_raw(logits.contiguous(), logits.dtype)
+        if target.shape != logits.shape:
+            raise RuntimeError("bce_with_logits: target shape %s != logits shape %s" % (tuple(target.shape),
+                                                                                        tuple(logits.shape)))
+        # elementwise pairing must follow the logits' physical order
+        if target.dim() == 4:
+            target = to_nhwc_raw(target, torch.float32)
+        else:
+            target = target.float().contiguous()
+        n = logits.numel()
+        dev = logits.device
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        ws = _workspace(query("ur_loss_workspace", n), dev)
+        call("ur_bce_fwd", logits.data_ptr(), _dt(logits), target.data_ptr(), n, out3.data_ptr(), ws.data_ptr(),
+             ws.numel(), _stream())
+        ctx.save_for_backward(logits, target)
+        return out3[2]
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target = ctx.saved_tensors
+        gout = gout.contiguous().float()
+        dlogits = torch.empty_like(logits, memory_format=torch.preserve_format)
+        call("ur_bce_bwd", logits.data_ptr(), _dt(logits), target.data_ptr(), logits.numel(), gout.data_ptr(),
+             dlogits.data_ptr(), _stream())
+        return dlogits, None
+
+
+def bce_with_logits(logits, target):
+    return _BCEWithLogits.apply(logits, target)
+
+
+def argmax_channels(logits):
+    """preds.argmax(1) for NHWC logits -> int64 [N,H,W] (first maximum wins)."""
+    _require_gpu(logits)
+    if logits.dim() == 4:
+        n, c, h, w = logits.shape
+        if not _is_nhwc_dense(logits):
+            logits = to_nhwc_raw(logits.contiguous(), logits.dtype)
+        out = torch.empty((n, h, w), dtype=torch.int64, device=logits.device)
+        rows = n * h * w
+    else:
+        rows, c = logits.shape
+        logits = logits.contiguous()
+        out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    call("ur_argmax_channels", logits.data_ptr(), _dt(logits), rows, c, c, out.data_ptr(), _stream())
+    return out
+
+
+def sigmoid_mask(logits):
+    """torch.sigmoid(x) > 0.5 -> bool tensor with the logits' shape and layout."""
+    _require_gpu(logits)
+    out = torch.empty_like(logits, dtype=torch.uint8, memory_format=torch.preserve_format)
+    if not (logits.is_contiguous() or (logits.dim() == 4 and _is_nhwc_dense(logits))):
+        raise RuntimeError("sigmoid_mask: logits must be dense")
+    call("ur_sigmoid_mask", logits.data_ptr(), _dt(logits), logits.numel(), out.data_ptr(), _stream())
+    return out.view(torch.bool)
