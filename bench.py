@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: U-ResNet Cityscapes-shaped 512x1024 bf16 training, images/sec.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one synthetic batch: NCHW fp32 images already resident in
+HBM -> UResNetNewEUCB(19, 3, 64) forward -> CE(ignore 255) -> backward -> [gradient all-reduce] ->
+Adam.  Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the implicit-GEMM
+convolution, forward + backward-data launches) timed live with events on its own stream;
+`cpu_baseline` is the oracle (plain PyTorch fp32 restatement of the reference) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (no sparsity)
+FP32_MATRIX_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=6, help="images per GPU (the reference's ablation script uses 6)")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(height, width):
+    """One training step of the oracle at batch 1, full resolution, on the host cores (rank 0 only)."""
+    import torch
+    from oracle import uresnet_oracle as O
+    torch.manual_seed(0)
+    model = O.UResNetNewEUCB(19, 3, 64).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 3, height, width, generator=g)
+    y = torch.randint(0, 19, (1, height, width), generator=g)
+    y[torch.rand(y.shape, generator=g) < 0.1] = 255
+    # warm-up on a quarter-size crop (allocators, mkldnn primitive caches), then one timed full-size step
+    O.seg_train_step(model, opt, x[:, :, :height // 2, :width // 2].contiguous(), y[:, :height // 2, :width // 2].contiguous())
+    t0 = time.perf_counter()
+    O.seg_train_step(model, opt, x, y)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 Adam training step, batch 1, 3x%dx%d fp32, oracle/uresnet_oracle.py UResNetNewEUCB(19,3,64); "
+                      "%.1f s" % (height, width, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import uresnet_amd
+    from uresnet_amd import ops, train
+    from uresnet_amd.modules.U_ResNet import UResNetNewEUCB
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    uresnet_amd._lib.load()
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = UResNetNewEUCB(19, 3, 64).set_compute_dtype(dtype).to(dev).train()
+    opt = train.Adam(model.parameters(), lr=1e-4)
+    ddp = uresnet_amd.ddp.DataParallel(model) if world > 1 else None
+
+    B, H, W = args.batch, args.height, args.width
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(B, 3, H, W, generator=g).to(dev)
+    y = torch.randint(0, 19, (B, H, W), generator=g)
+    y[torch.rand(y.shape, generator=g) < 0.1] = 255
+    y = y.to(dev)
+
+    def step():
+        if ddp is None:
+            return train.seg_train_step(model, opt, x, y)
+        return train.seg_train_step(model, opt, x, y, count_hook=ddp.count_hook, grad_hook=ddp.finish)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, _ = step()
+    fence()
+    if not args.no_kernel_timing:
+        ops.kernel_timings = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timings, ops.kernel_timings = ops.kernel_timings, None
+    final_loss = float(loss.item())
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        peak = BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else FP32_MATRIX_PEAK_TFLOPS
+        kernels = {}
+        for tag, flops, e0, e1 in (timings or []):
+            k = kernels.setdefault(tag, [0, 0.0, 0.0])
+            k[0] += 1
+            k[1] += flops
+            k[2] += e0.elapsed_time(e1) * 1e-3
+        roof = None
+        if kernels:
+            ig = [kernels.get("igemm_fwd", [0, 0.0, 0.0]), kernels.get("igemm_dgrad", [0, 0.0, 0.0])]
+            launches = ig[0][0] + ig[1][0]
+            flops = ig[0][1] + ig[1][1]
+            secs = ig[0][2] + ig[1][2]
+            achieved = flops / secs / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + backward-data launches)",
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "traffic": None, "launches": launches, "avg_launch_ms": round(secs / launches * 1e3, 4),
+                    "flops_per_launch": flops / launches,
+                    "time_share_of_step": round(secs / elapsed, 3)}
+            wg = kernels.get("wgrad")
+            if wg:
+                roof["wgrad_kernel"] = {"achieved": round(wg[1] / wg[2] / 1e12, 2), "frac": round(wg[1] / wg[2] / 1e12 / peak, 4),
+                                        "launches": wg[0], "avg_launch_ms": round(wg[2] / wg[0] * 1e3, 4),
+                                        "time_share_of_step": round(wg[2] / elapsed, 3)}
+            conv_flops = sum(k[1] for k in kernels.values())
+            conv_secs = sum(k[2] for k in kernels.values())
+            roof["all_conv_mfma_util"] = round(conv_flops / conv_secs / 1e12 / peak, 4)
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(H, W)
+        out = {
+            "metric": "train images/sec (node) Cityscapes 512x1024 bf16 @1/2/4/8 GPU; conv MFMA util %",
+            "value": round(world * B * args.steps / elapsed, 3),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[2]: U-ResNet Cityscapes %dx%d segmentation (19 classes), "
+                                   "UResNetNewEUCB(19,3,64) training step: forward + CE(ignore 255) + backward + Adam(1e-4)"
+                                   % (H, W),
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "bn": "per-replica batch statistics", "final_loss": round(final_loss, 5)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,8 +109,9 @@ int ur_gconv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace,
 size_t ur_bn_stats_rows(long long rows, int c);          /* rows of partials ur_bn_stats writes */
 int ur_bn_stats(const void* y, int dtype, long long rows, int c, float* partial, ur_stream_t s);
 /* reduce partial[nparts][c][2] -> mean, invstd; update running stats (and increment the
- * num_batches_tracked counter) where the pointers are non-NULL */
-int ur_bn_finalize(const float* partial, int nparts, long long count, int c, float eps, float momentum,
+ * num_batches_tracked counter) where the pointers are non-NULL.  `partial` is used as scratch
+ * (long partial lists are folded in place first). */
+int ur_bn_finalize(float* partial, int nparts, long long count, int c, float eps, float momentum,
                    float* mean, float* invstd, float* running_mean, float* running_var,
                    long long* num_batches_tracked, ur_stream_t s);
 /* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
@@ -122,8 +123,8 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
 /* backward pass 1: partial[nparts][c][2] = (sum g, sum g*xhat), g = dz * (z > 0 if act) */
 int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
                          int act, int dtype, long long rows, int c, float* partial, ur_stream_t s);
-/* sums[c][2] = reduce(partial); dgamma = sums[.,1]; dbeta = sums[.,0] */
-int ur_bn_bwd_finalize(const float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
+/* sums[c][2] = reduce(partial); dgamma = sums[.,1]; dbeta = sums[.,0]; `partial` is used as scratch */
+int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
                        ur_stream_t s);
 /* backward pass 2: dy = gamma*invstd*(g - sums0/count - xhat*sums1/count); dres = g (optional).
  * eval != 0 treats the statistics as constants: dy = gamma*invstd*g. */

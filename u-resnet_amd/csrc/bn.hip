@@ -98,6 +98,46 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
     colreduce_body<VEC, 2>(op, rows, C, partial);
 }
 
+// Fold partial[nparts][C][NV] down to its first `chunks` rows in place: workgroup (b, cgroup) owns rows
+// b, b+chunks, b+2*chunks, ... of 32 channels (8 row slots x 32 channels, coalesced 32*NV-float reads),
+// sums them in double in a fixed order and overwrites row b -- the only row of its set any workgroup writes.
+template <int NV>
+__global__ __launch_bounds__(256) void fold_partials_kernel(float* __restrict__ partial, int nparts, int C, int chunks) {
+    __shared__ double red[8][32][NV];
+    const int b = blockIdx.x, c = blockIdx.y * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    if (c < C) {
+        for (int p = b + slot * chunks; p < nparts; p += 8 * chunks) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] += (double)partial[((size_t)p * C + c) * NV + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[slot][threadIdx.x & 31][k] = acc[k];
+    __syncthreads();
+    if (slot == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double s = 0.0;
+            for (int sl = 0; sl < 8; ++sl) s += red[sl][threadIdx.x][k];
+            partial[((size_t)b * C + c) * NV + k] = (float)s;
+        }
+    }
+}
+
+constexpr int FOLD_CHUNKS = 32;
+
+// returns the number of partial rows left after folding (launches nothing when already small)
+template <int NV>
+int fold_partials(float* partial, int nparts, int C, hipStream_t st) {
+    if (nparts <= FOLD_CHUNKS * 2) return nparts;
+    hipLaunchKernelGGL((fold_partials_kernel<NV>), dim3(FOLD_CHUNKS, (C + 31) / 32), dim3(256), 0, st, partial, nparts, C,
+                       FOLD_CHUNKS);
+    return FOLD_CHUNKS;
+}
+
 // out[c][k] = sum_p partial[p][c][k] in double; optional mean/invstd/running-stat epilogue
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, long long count, int C, float eps,
                                    float momentum, float* __restrict__ mean, float* __restrict__ invstd,
@@ -261,15 +301,19 @@ int ur_colsum(const void* x, int dtype, long long rows, int c, int ld, float* ou
         else hipLaunchKernelGGL((colsum_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, rows, c, ld, partial);
     });
     if (int e = ur_check_launch("colsum")) return e;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ur_cdiv(c, 128)), dim3(128), 0, (hipStream_t)s, partial, grid, c, 1,
+    const int nparts = fold_partials<1>(partial, grid, c, (hipStream_t)s);
+    if (int e = ur_check_launch("colsum_fold_partials")) return e;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, c, 1,
                        (float*)nullptr, out, (float*)nullptr);
     return ur_check_launch("colsum_finalize");
 }
 
-int ur_bn_finalize(const float* partial, int nparts, long long count, int c, float eps, float momentum, float* mean,
+int ur_bn_finalize(float* partial, int nparts, long long count, int c, float eps, float momentum, float* mean,
                    float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
                    ur_stream_t s) {
     UR_REQUIRE(partial && mean && invstd && nparts > 0 && count > 0 && c > 0, "bn_finalize: bad arguments");
+    nparts = fold_partials<2>(partial, nparts, c, (hipStream_t)s);
+    if (int e = ur_check_launch("bn_fold_partials")) return e;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, count, c,
                        eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
     return ur_check_launch("bn_finalize");
@@ -313,9 +357,11 @@ int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const flo
     return ur_check_launch("bn_act_bwd_reduce");
 }
 
-int ur_bn_bwd_finalize(const float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
+int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
                        ur_stream_t s) {
     UR_REQUIRE(partial && sums && nparts > 0 && c > 0, "bn_bwd_finalize: bad arguments");
+    nparts = fold_partials<2>(partial, nparts, c, (hipStream_t)s);
+    if (int e = ur_check_launch("bn_fold_partials")) return e;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, c, 2,
                        sums, dbeta, dgamma);
     return ur_check_launch("bn_bwd_finalize");

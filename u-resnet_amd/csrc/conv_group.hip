@@ -52,6 +52,77 @@ __global__ __launch_bounds__(NT) void gconv3x3_kernel(const T* __restrict__ in, 
     }
 }
 
+// Same arithmetic with the quad's weights held in registers: when the number of quads divides the
+// workgroup size every thread keeps ONE quad for its whole grid-stride walk over pixels, so the
+// 36 / 144 weights are loaded once per thread instead of once per pixel.
+template <typename T, int CPG, bool DGRAD>
+__global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                           T* __restrict__ out, int N, int H, int W, int C) {
+    constexpr int NV = 4 * CPG;
+    const int Q = C / 4;                         // Q divides NT (checked on the host)
+    const int q = threadIdx.x % Q, pslot = threadIdx.x / Q, PS = NT / Q;
+    float wr[9][NV];
+    const float* wq = w + (size_t)q * 4 * CPG * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if constexpr (CPG == 1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wr[tap][a] = wq[a * 9 + tap];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) wr[tap][a * 4 + b] = DGRAD ? wq[(b * 4 + a) * 9 + tap] : wq[(a * 4 + b) * 9 + tap];
+        }
+    }
+    const long long P = (long long)N * H * W;
+    for (long long pix = (long long)blockIdx.x * PS + pslot; pix < P; pix += (long long)gridDim.x * PS) {
+        const int x = (int)(pix % W);
+        const long long t = pix / W;
+        const int y = (int)(t % H), n = (int)(t / H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = DGRAD ? y + 1 - ky : y + ky - 1;
+            const bool yok = (unsigned)yy < (unsigned)H;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = DGRAD ? x + 1 - kx : x + kx - 1;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yok && (unsigned)xx < (unsigned)W) v = ur_load4(in + (((long long)n * H + yy) * W + xx) * C + q * 4);
+                const float vi[4] = {v.x, v.y, v.z, v.w};
+                const int tap = ky * 3 + kx;
+                if constexpr (CPG == 1) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] += vi[a] * wr[tap][a];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a] += vi[b] * wr[tap][a * 4 + b];
+                }
+            }
+        }
+        ur_store4(out + pix * C + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+}
+
+template <typename T, bool DGRAD>
+void launch_gconv(const T* in, const float* w, T* out, int n, int h, int w_, int c, int cpg, hipStream_t st) {
+    const int Q = c / 4;
+    const long long P = (long long)n * h * w_;
+    if (NT % Q == 0) {
+        const int PS = NT / Q;
+        const int grid = ur_grid_1d(P, PS, 256 * 8);
+        if (cpg == 1) hipLaunchKernelGGL((gconv3x3_regw_kernel<T, 1, DGRAD>), dim3(grid), dim3(NT), 0, st, in, w, out, n, h, w_, c);
+        else hipLaunchKernelGGL((gconv3x3_regw_kernel<T, 4, DGRAD>), dim3(grid), dim3(NT), 0, st, in, w, out, n, h, w_, c);
+    } else {
+        const int grid = ur_grid_1d(P * Q, NT);
+        if (cpg == 1) hipLaunchKernelGGL((gconv3x3_kernel<T, 1, DGRAD>), dim3(grid), dim3(NT), 0, st, in, w, out, n, h, w_, c);
+        else hipLaunchKernelGGL((gconv3x3_kernel<T, 4, DGRAD>), dim3(grid), dim3(NT), 0, st, in, w, out, n, h, w_, c);
+    }
+}
+
 // Backward-weight: thread (slot, quad) accumulates its quad's CPG*4*9 products over the pixels
 // slot, slot+S, ...; the slots of a workgroup are summed through LDS in a fixed order and each
 // workgroup writes one partial row partial[block][C*CPG*9] (layout = PyTorch weight layout).
@@ -159,23 +230,13 @@ extern "C" {
 
 int ur_gconv3x3_fwd(const void* x, const float* w, void* y, int dtype, int n, int h, int w_, int c, int cpg, ur_stream_t s) {
     if (int e = check_args(x, w, y, dtype, n, h, w_, c, cpg)) return e;
-    const long long total = (long long)n * h * w_ * (c / 4);
-    const int grid = ur_grid_1d(total, NT);
-    UR_DISPATCH_DTYPE(dtype, {
-        if (cpg == 1) hipLaunchKernelGGL((gconv3x3_kernel<T, 1, false>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, w, (T*)y, n, h, w_, c);
-        else hipLaunchKernelGGL((gconv3x3_kernel<T, 4, false>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, w, (T*)y, n, h, w_, c);
-    });
+    UR_DISPATCH_DTYPE(dtype, (launch_gconv<T, false>((const T*)x, w, (T*)y, n, h, w_, c, cpg, (hipStream_t)s)));
     return ur_check_launch("gconv3x3_fwd");
 }
 
 int ur_gconv3x3_dgrad(const void* dy, const float* w, void* dx, int dtype, int n, int h, int w_, int c, int cpg, ur_stream_t s) {
     if (int e = check_args(dy, w, dx, dtype, n, h, w_, c, cpg)) return e;
-    const long long total = (long long)n * h * w_ * (c / 4);
-    const int grid = ur_grid_1d(total, NT);
-    UR_DISPATCH_DTYPE(dtype, {
-        if (cpg == 1) hipLaunchKernelGGL((gconv3x3_kernel<T, 1, true>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dy, w, (T*)dx, n, h, w_, c);
-        else hipLaunchKernelGGL((gconv3x3_kernel<T, 4, true>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dy, w, (T*)dx, n, h, w_, c);
-    });
+    UR_DISPATCH_DTYPE(dtype, (launch_gconv<T, true>((const T*)dy, w, (T*)dx, n, h, w_, c, cpg, (hipStream_t)s)));
     return ur_check_launch("gconv3x3_dgrad");
 }
 

@@ -162,6 +162,37 @@ class PackedWeights:
         return packed
 
 
+# Optional live kernel timing: when `kernel_timings` is a list, every dense-conv kernel launch is
+# bracketed by two events recorded on the stream it is launched on, together with its algorithmic FLOPs.
+kernel_timings = None
+
+
+class _Timed:
+    __slots__ = ("tag", "flops", "e0")
+
+    def __init__(self, tag, flops):
+        self.tag, self.flops, self.e0 = tag, flops, None
+
+    def __enter__(self):
+        if kernel_timings is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            kernel_timings.append((self.tag, self.flops, self.e0, e1))
+        return False
+
+
+def _conv_flops(d, transposed=False):
+    if transposed:
+        return 2.0 * d.n * d.h * d.w * d.cin * d.cout * 4
+    return 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -189,7 +220,8 @@ class _Conv2d(Function):
         if want_stats:
             rows = query("ur_conv2d_stats_rows", C.byref(d))
             stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
-        call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
+        with _Timed("igemm_fwd", _conv_flops(d)):
+            call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
         ctx.save_for_backward(x, weight)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
         if want_stats:
@@ -206,12 +238,14 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             wp = ctx.packs.get(weight, d, _lib.PACK_DGRAD)
             dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
-            call("ur_conv2d_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+            with _Timed("igemm_dgrad", _conv_flops(d)):
+                call("ur_conv2d_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = _workspace(query("ur_conv2d_wgrad_workspace", C.byref(d)), x.device)
-            call("ur_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
-                 C.byref(d), _stream())
+            with _Timed("wgrad", _conv_flops(d)):
+                call("ur_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                     C.byref(d), _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, d.cout, d.cout, x.device)
         return dx, dw, db, None, None, None, None
@@ -233,7 +267,8 @@ class _ConvT2x2(Function):
         d = _desc(x.shape, cout, 2, 2, 2, 0, x.dtype, oh=2 * h, ow=2 * w)
         wp = packs.get(weight, d, _lib.PACK_CONVT_FWD)
         y = empty_nhwc(n, cout, 2 * h, 2 * w, x.dtype, x.device)
-        call("ur_convT2x2_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), C.byref(d), _stream())
+        with _Timed("igemm_fwd", _conv_flops(d, True)):
+            call("ur_convT2x2_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), C.byref(d), _stream())
         ctx.save_for_backward(x, weight)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
         return y
@@ -247,12 +282,14 @@ class _ConvT2x2(Function):
         if ctx.needs_input_grad[0]:
             wp = ctx.packs.get(weight, d, _lib.PACK_CONVT_DGRAD)
             dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
-            call("ur_convT2x2_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+            with _Timed("igemm_dgrad", _conv_flops(d, True)):
+                call("ur_convT2x2_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = _workspace(query("ur_convT2x2_wgrad_workspace", C.byref(d)), x.device)
-            call("ur_convT2x2_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
-                 C.byref(d), _stream())
+            with _Timed("wgrad", _conv_flops(d, True)):
+                call("ur_convT2x2_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                     C.byref(d), _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, d.cout, d.cout, x.device)
         return dx, dw, db, None
