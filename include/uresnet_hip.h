@@ -74,6 +74,19 @@ size_t ur_conv2d_wgrad_workspace(const ur_conv_desc* d);
 int ur_conv2d_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
                     const ur_conv_desc* d, ur_stream_t s);
 
+/* ---------------------------------------------------------------- 3x3 / stride 1 / pad 1, bf16: LDS-tiled kernel
+ * Same contract as ur_conv2d_fwd / ur_conv2d_dgrad for the layers that carry ~94 % of the FLOPs
+ * (S/C:94,97,140,143 with 64..1024 channels): needs 64 | produced channels, 32 | reduced channels.
+ * Weights are packed in MFMA-fragment order (dgrad != 0: tap-flipped and transposed). */
+int ur_conv3x3_tile_supported(const ur_conv_desc* d, int dgrad);
+size_t ur_conv3x3_tile_packed_elems(const ur_conv_desc* d);
+int ur_conv3x3_tile_pack_weight(const float* w, void* packed, const ur_conv_desc* d, int dgrad, ur_stream_t s);
+int ur_conv3x3_tile_stats_rows(const ur_conv_desc* d);
+int ur_conv3x3_tile_fwd(const void* x, const void* w_packed, void* y, float* stats, const ur_conv_desc* d,
+                        ur_stream_t s);
+int ur_conv3x3_tile_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const ur_conv_desc* d,
+                          ur_stream_t s);
+
 /* ---------------------------------------------------------------- ConvTranspose2d(k=2, s=2) + bias
  * Replaces aten::conv_transpose2d of `Up.up` (S/C:113,117).  d describes the transposed
  * convolution itself: input (n,h,w,cin) -> output (n,2h,2w,cout); kh=kw=stride=2, pad=0.

@@ -54,6 +54,8 @@ CONV_SHAPES = [
     # n, cin, h, w, cout, k, stride, pad, bias
     (2, 64, 16, 32, 64, 3, 1, 1, False),
     (1, 128, 9, 13, 192, 3, 1, 1, False),      # ragged spatial size, two column tiles
+    (1, 64, 20, 70, 128, 3, 1, 1, False),      # ragged in both directions, three tile columns
+    (1, 256, 8, 32, 64, 3, 1, 1, False),       # eight 32-channel slices
     (2, 3, 17, 19, 64, 3, 1, 1, False),        # Cin = 3 (scalar gather)
     (2, 3, 32, 32, 64, 7, 2, 3, False),        # stem
     (2, 64, 16, 16, 128, 3, 2, 1, False),      # strided ResBlock conv
@@ -100,6 +102,28 @@ def test_conv2d_fwd_bwd(pkg, shape, dtype):
     yf = yr.detach().double()
     assert rel_l2(st[:, 0], yf.sum((0, 2, 3))) < 5e-3 + tol
     assert rel_l2(st[:, 1], (yf * yf).sum((0, 2, 3))) < 5e-3 + tol
+
+
+def test_tiled_3x3_kernel_agrees_with_generic_kernel(pkg):
+    """The LDS-tiled bf16 3x3 kernel and the generic implicit-GEMM kernel see identical bf16 inputs and
+    accumulate in fp32: they must agree to fp32 summation-order round-off (then one bf16 rounding)."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 128, 24, 40, generator=g).to(DEV)
+    wt = (torch.randn(64, 128, 3, 3, generator=g) / 34.0).to(DEV)
+    gy = torch.randn(2, 64, 24, 40, generator=g).to(DEV)
+    res = {}
+    for tile in (True, False):
+        pkg.ops.use_tile_kernel = tile
+        try:
+            xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+            y, st = pkg.ops.conv2d(pkg.ops.as_activation(xd, torch.bfloat16), wd, None, pkg.ops.PackedWeights(), 1, 1, True)
+            (y.float() * pkg.ops.to_nhwc_raw(gy, torch.float32)).sum().backward()
+            res[tile] = (host(pkg, y), xd.grad.cpu(), st.sum(0).cpu())
+        finally:
+            pkg.ops.use_tile_kernel = True
+    assert rel_l2(res[True][0], res[False][0]) < 2e-3          # bf16 outputs: differ by at most 1 ulp here and there
+    assert rel_l2(res[True][1], res[False][1]) < 2e-3
+    assert rel_l2(res[True][2], res[False][2]) < 1e-5          # fp32 epilogue statistics
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -38,6 +38,12 @@ SIGNATURES = {
     "ur_conv2d_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
     "ur_conv2d_wgrad_workspace": (_sz, [_dp]),
     "ur_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
+    "ur_conv3x3_tile_supported": (_i, [_dp, _i]),
+    "ur_conv3x3_tile_packed_elems": (_sz, [_dp]),
+    "ur_conv3x3_tile_pack_weight": (_i, [_vp, _vp, _dp, _i, _vp]),
+    "ur_conv3x3_tile_stats_rows": (_i, [_dp]),
+    "ur_conv3x3_tile_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
+    "ur_conv3x3_tile_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
     "ur_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_convT2x2_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
     "ur_convT2x2_wgrad_workspace": (_sz, [_dp]),

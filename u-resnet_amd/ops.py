@@ -149,6 +149,18 @@ class PackedWeights:
     def __init__(self):
         self._cache = {}
 
+    def get_tile(self, weight, d, dgrad):
+        """Fragment-order image for the LDS-tiled 3x3 kernel."""
+        mode = "tile_dgrad" if dgrad else "tile_fwd"
+        key = (weight.data_ptr(), weight._version, _weights_epoch, d.dtype, d.cin, d.cout)
+        hit = self._cache.get(mode)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        packed = torch.empty(query("ur_conv3x3_tile_packed_elems", C.byref(d)), dtype=torch.bfloat16, device=weight.device)
+        call("ur_conv3x3_tile_pack_weight", weight.data_ptr(), packed.data_ptr(), C.byref(d), int(dgrad), _stream())
+        self._cache[mode] = (key, packed)
+        return packed
+
     def get(self, weight, d, mode):
         key = (weight.data_ptr(), weight._version, _weights_epoch, d.dtype, d.cin, d.cout)
         hit = self._cache.get(mode)
@@ -165,6 +177,7 @@ class PackedWeights:
 # Optional live kernel timing: when `kernel_timings` is a list, every dense-conv kernel launch is
 # bracketed by two events recorded on the stream it is launched on, together with its algorithmic FLOPs.
 kernel_timings = None
+use_tile_kernel = True          # False forces the generic implicit-GEMM kernel (A/B comparisons, tests)
 
 
 class _Timed:
@@ -214,14 +227,22 @@ class _Conv2d(Function):
         d = _desc(x.shape, cout, kh, kw, stride, pad, x.dtype)
         if d.oh <= 0 or d.ow <= 0:
             raise RuntimeError("conv2d: kernel %dx%d does not fit input %dx%d" % (kh, kw, d.h, d.w))
-        wp = packs.get(weight, d, _lib.PACK_FWD)
         y = empty_nhwc(d.n, cout, d.oh, d.ow, x.dtype, x.device)
         stats = None
-        if want_stats:
-            rows = query("ur_conv2d_stats_rows", C.byref(d))
-            stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
-        with _Timed("igemm_fwd", _conv_flops(d)):
-            call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
+        if bias is None and use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 0):
+            wp = packs.get_tile(weight, d, False)
+            if want_stats:
+                rows = query("ur_conv3x3_tile_stats_rows", C.byref(d))
+                stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
+            with _Timed("tile_fwd", _conv_flops(d)):
+                call("ur_conv3x3_tile_fwd", x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(stats), C.byref(d), _stream())
+        else:
+            wp = packs.get(weight, d, _lib.PACK_FWD)
+            if want_stats:
+                rows = query("ur_conv2d_stats_rows", C.byref(d))
+                stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
+            with _Timed("igemm_fwd", _conv_flops(d)):
+                call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
         ctx.save_for_backward(x, weight)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
         if want_stats:
@@ -236,10 +257,15 @@ class _Conv2d(Function):
         dy = _g(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wp = ctx.packs.get(weight, d, _lib.PACK_DGRAD)
             dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
-            with _Timed("igemm_dgrad", _conv_flops(d)):
-                call("ur_conv2d_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+            if use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 1):
+                wp = ctx.packs.get_tile(weight, d, True)
+                with _Timed("tile_dgrad", _conv_flops(d)):
+                    call("ur_conv3x3_tile_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+            else:
+                wp = ctx.packs.get(weight, d, _lib.PACK_DGRAD)
+                with _Timed("igemm_dgrad", _conv_flops(d)):
+                    call("ur_conv2d_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = _workspace(query("ur_conv2d_wgrad_workspace", C.byref(d)), x.device)
