@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--per-shape", action="store_true", help="print per-(kernel, shape) conv timings to stderr")
     return ap.parse_args()
 
 
@@ -125,7 +126,10 @@ def main():
     if rank == 0:
         peak = BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else FP32_MATRIX_PEAK_TFLOPS
         kernels = {}
-        for tag, flops, e0, e1 in (timings or []):
+        shapes = {}
+        for tag, flops, e0, e1, shape in (timings or []):
+            sk = shapes.setdefault((tag, shape), [0, 0.0, 0.0])
+            sk[0] += 1; sk[1] += flops; sk[2] += e0.elapsed_time(e1) * 1e-3
             k = kernels.setdefault(tag, [0, 0.0, 0.0])
             k[0] += 1
             k[1] += flops
@@ -135,7 +139,8 @@ def main():
             groups = {
                 "conv3x3_tile_kernel (3x3 s1 p1 forward + backward-data launches)": ("tile_fwd", "tile_dgrad"),
                 "conv_igemm_kernel (generic implicit GEMM: stem, 1x1, ConvT, skinny layers)": ("igemm_fwd", "igemm_dgrad"),
-                "conv_wgrad_kernel (+ slab reduce)": ("wgrad",),
+                "wgrad3x3_tile_kernel (3x3 s1 p1 backward-weight + slab reduce)": ("tile_wgrad",),
+                "conv_wgrad_kernel (generic backward-weight + slab reduce)": ("wgrad",),
             }
             summary = {}
             for name, tags in groups.items():
@@ -156,6 +161,9 @@ def main():
             conv_secs = sum(k[2] for k in kernels.values())
             roof["all_conv_mfma_util"] = round(conv_flops / conv_secs / 1e12 / peak, 4)
             roof["all_conv_time_share_of_step"] = round(conv_secs / elapsed, 3)
+        if args.per_shape:
+            for (tag, shape), (n, fl, sec) in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:40]:
+                print("%-12s %-34s calls %4d  %8.3f ms/step  %7.1f TF" % (tag, shape, n, sec / args.steps * 1e3, fl / sec / 1e12), file=sys.stderr)
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(H, W)

@@ -87,6 +87,12 @@ int ur_conv3x3_tile_fwd(const void* x, const void* w_packed, void* y, float* sta
 int ur_conv3x3_tile_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const ur_conv_desc* d,
                           ur_stream_t s);
 
+/* backward-weight counterpart (same contract as ur_conv2d_wgrad; needs 64 | cin and 64 | cout) */
+int ur_wgrad3x3_tile_supported(const ur_conv_desc* d);
+size_t ur_wgrad3x3_tile_workspace(const ur_conv_desc* d);
+int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
+                     const ur_conv_desc* d, ur_stream_t s);
+
 /* ---------------------------------------------------------------- ConvTranspose2d(k=2, s=2) + bias
  * Replaces aten::conv_transpose2d of `Up.up` (S/C:113,117).  d describes the transposed
  * convolution itself: input (n,h,w,cin) -> output (n,2h,2w,cout); kh=kw=stride=2, pad=0.

@@ -118,12 +118,13 @@ def test_tiled_3x3_kernel_agrees_with_generic_kernel(pkg):
             xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
             y, st = pkg.ops.conv2d(pkg.ops.as_activation(xd, torch.bfloat16), wd, None, pkg.ops.PackedWeights(), 1, 1, True)
             (y.float() * pkg.ops.to_nhwc_raw(gy, torch.float32)).sum().backward()
-            res[tile] = (host(pkg, y), xd.grad.cpu(), st.sum(0).cpu())
+            res[tile] = (host(pkg, y), xd.grad.cpu(), st.sum(0).cpu(), wd.grad.cpu())
         finally:
             pkg.ops.use_tile_kernel = True
     assert rel_l2(res[True][0], res[False][0]) < 2e-3          # bf16 outputs: differ by at most 1 ulp here and there
     assert rel_l2(res[True][1], res[False][1]) < 2e-3
     assert rel_l2(res[True][2], res[False][2]) < 1e-5          # fp32 epilogue statistics
+    assert rel_l2(res[True][3], res[False][3]) < 1e-5          # fp32 weight gradients from identical bf16 operands
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -44,6 +44,9 @@ SIGNATURES = {
     "ur_conv3x3_tile_stats_rows": (_i, [_dp]),
     "ur_conv3x3_tile_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
+    "ur_wgrad3x3_tile_supported": (_i, [_dp]),
+    "ur_wgrad3x3_tile_workspace": (_sz, [_dp]),
+    "ur_wgrad3x3_tile": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
     "ur_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_convT2x2_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
     "ur_convT2x2_wgrad_workspace": (_sz, [_dp]),

@@ -1,0 +1,237 @@
+// Backward-weight of the 3x3 / stride 1 / pad 1 convolutions, bf16 NHWC, LDS-tiled on the bf16 MFMA.
+//
+//   dW[co][ci][tap] = sum_pixels dy[p][co] * x[p + tap - 1][ci]
+// Workgroup (4 waves) owns a 64(co) x 64(ci) x 9(tap) block of dW and a strided subset of the
+// 4 x 32-pixel spatial tiles (split over gridDim.y).  Per tile it stages the dy tile [128 px][64 co]
+// and the x halo [6 x 34 px][64 ci] in LDS once; the halo then serves all nine taps, so every
+// staged element feeds 9 x 64 MACs.  The reduction index of the GEMM is the pixel, while memory is
+// channel-contiguous, so both MFMA operands are fetched with the transposing LDS read
+// ds_read_b64_tr_b16.  LDS rows are 128 B per pixel with the two 64-byte halves swapped on every
+// second pixel pair (conflict-free for the 4-pixel x 64-byte blocks a transposing read touches); the halo
+// row pitch is 36 pixels so every read address is a per-lane constant plus a compile-time immediate.
+// Wave (a, b) accumulates co-half a x ci-half b for all 9 taps (9 x 16 accumulator registers);
+// 72 MFMAs per tile per wave.  Partial blocks go to one fp32 slab per split and are summed in a
+// fixed order by a second kernel that also transposes to PyTorch's [co][ci][ky][kx].
+#include "ur_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TW = 32, BO = 64, BI = 64, NTHREADS = 256;
+constexpr int HPITCH = 36;                                 // halo row pitch in pixels (34 used)
+constexpr int HALO_COLS = TW + 2;
+
+struct WgTileParams {
+    const bf16_t* x;     // [N][H][W][ld_x]
+    const bf16_t* dy;    // [N][H][W][ld_dy]
+    float* ws;           // [nsplit][Cout][9][Cin]
+    int N, H, W, Cin, Cout, ld_x, ld_dy;
+    int tiles_x, tiles_y, tiles;
+    int ci_blocks;
+};
+
+// byte offset of channel c (multiple of 4) of pixel `pix` inside an image with 128-byte pixel rows
+__device__ __forceinline__ int swz(int pix, int c) {
+    return pix * 128 + ((((c >> 5) ^ (pix >> 1)) & 1) << 6) + (c & 31) * 2;
+}
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* base0, const unsigned char* base1, int imm) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base0 + imm));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base1 + imm));
+    s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, both);
+}
+
+template <int TH, int MINW>
+__global__ __launch_bounds__(NTHREADS, MINW) void wgrad3x3_tile_kernel(WgTileParams p) {
+    constexpr int DY_PIX = TH * TW, HALO_ROWS = TH + 2;
+    constexpr int DY_BYTES = DY_PIX * 128, HALO_BYTES = HALO_ROWS * HPITCH * 128;
+    constexpr int DY_ITERS = DY_PIX * 8 / NTHREADS;
+    constexpr int HALO_ITERS = (HALO_ROWS * HALO_COLS * 8 + NTHREADS - 1) / NTHREADS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DY_BYTES + HALO_BYTES];
+    unsigned char* dyl = lds;
+    unsigned char* xl = lds + DY_BYTES;
+
+    const int pair = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int cob = pair / p.ci_blocks, cib = pair - cob * p.ci_blocks;
+    const int co0 = cob * BO, ci0 = cib * BI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+
+    // ---- staging: piece i = tid + 256 j covers channels (tid & 7) * 8 .. +8 of pixel i >> 3; the pixel
+    // coordinates are recomputed per tile (a few integer ops) rather than held in registers ------------
+    const int piece = tid & 7, piece_ch = piece * 8;
+
+    bf16x8_t pd[DY_ITERS], ph[HALO_ITERS];
+    auto prefetch = [&](int tile) {
+        const int img = tile / (p.tiles_y * p.tiles_x);
+        const int trem = tile - img * (p.tiles_y * p.tiles_x);
+        const int ty0 = (trem / p.tiles_x) * TH, tx0 = (trem % p.tiles_x) * TW;
+        const bf16_t* dyb = p.dy + (size_t)img * p.H * p.W * p.ld_dy + co0 + piece_ch;
+        const bf16_t* xb = p.x + (size_t)img * p.H * p.W * p.ld_x + ci0 + piece_ch;
+#pragma unroll
+        for (int j = 0; j < DY_ITERS; ++j) {
+            const int pix = (tid >> 3) + j * (NTHREADS / 8);
+            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
+            if (oy < p.H && ox < p.W) pd[j] = *reinterpret_cast<const bf16x8_t*>(dyb + ((size_t)oy * p.W + ox) * p.ld_dy);
+            else pd[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < HALO_ITERS; ++j) {
+            const int hp = (tid >> 3) + j * (NTHREADS / 8);
+            const int hy = hp / HALO_COLS, hx = hp - hy * HALO_COLS;
+            const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+            if (hp < HALO_ROWS * HALO_COLS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                ph[j] = *reinterpret_cast<const bf16x8_t*>(xb + ((size_t)gy * p.W + gx) * p.ld_x);
+            else ph[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < DY_ITERS; ++j) {
+            const int pix = (tid >> 3) + j * (NTHREADS / 8);
+            *reinterpret_cast<bf16x8_t*>(dyl + swz(pix, piece_ch)) = pd[j];
+        }
+#pragma unroll
+        for (int j = 0; j < HALO_ITERS; ++j) {
+            const int hp = (tid >> 3) + j * (NTHREADS / 8);
+            const int hy = hp / HALO_COLS, hx = hp - hy * HALO_COLS;
+            if (hp < HALO_ROWS * HALO_COLS) *reinterpret_cast<bf16x8_t*>(xl + swz(hy * HPITCH + hx, piece_ch)) = ph[j];
+        }
+    };
+
+    // ---- transposing-read lane constants ---------------------------------------------------------------
+    // 16-lane group g: pixels 8*(g>>1) + q (+4 for the second read), channels 16*(g&1) + 4*p', lane = 4q + p'
+    const int g = lane >> 4, li = lane & 15;
+    const int lpix = 8 * (g >> 1) + (li >> 2), lch = 16 * (g & 1) + 4 * (li & 3);
+    const unsigned char* a_base[2];
+    const unsigned char* b_base[3][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        a_base[s] = dyl + swz(lpix + 4 * s, wa * 32 + lch);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) b_base[dx][s] = xl + swz(lpix + 4 * s + dx, wb * 32 + lch);
+    }
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int tile = split;
+    if (tile < p.tiles) prefetch(tile);
+    for (; tile < p.tiles; tile += nsplit) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (tile + nsplit < p.tiles) prefetch(tile + nsplit);
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx) {
+                // pixel bases are multiples of 4, so they do not disturb the lane-constant swizzle bits
+                const bf16x8_t af = tr_frag(a_base[0], a_base[1], (r * TW + kx * 16) * 128);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const bf16x8_t bfr = tr_frag(b_base[dx][0], b_base[dx][1], ((r + dy) * HPITCH + kx * 16) * 128);
+                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[dy * 3 + dx], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- partial block -> slab [split][co][tap][ci] ------------------------------------------------------
+    const int lx = lane & 31, lh = lane >> 5;
+    float* slab = p.ws + (size_t)split * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[((size_t)co * 9 + t) * p.Cin + ci0 + wb * 32 + lx] = acc[t][r];
+        }
+}
+
+// dw[co][ci][tap] = sum_s ws[s][co][tap][ci]
+__global__ void wgrad3x3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int nsplit) {
+    const long long per = (long long)Cout * 9 * Cin;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < per; idx += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % Cin);
+        const long long t = idx / Cin;
+        const int tap = (int)(t % 9), co = (int)(t / 9);
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * per + idx];
+        dw[((long long)co * Cin + ci) * 9 + tap] = s;
+    }
+}
+
+struct Plan { int pairs, nsplit, tiles; };
+
+// Tile height: 2 rows (two workgroups per CU; measured 4 % faster) or 4 rows (one workgroup per CU,
+// accumulators in AGPRs) when URESNET_WGRAD_TH=4 is set for A/B runs.
+int tile_rows() {
+    static const int th = [] { const char* e = getenv("URESNET_WGRAD_TH"); return (e && e[0] == '4') ? 4 : 2; }();
+    return th;
+}
+
+Plan make_plan(const ur_conv_desc* d) {
+    Plan pl;
+    pl.pairs = (d->cout / BO) * (d->cin / BI);
+    pl.tiles = d->n * ur_cdiv(d->h, tile_rows()) * ur_cdiv(d->w, TW);
+    int want = (512 + pl.pairs - 1) / pl.pairs;          // two resident workgroups per CU; fewer, larger slabs
+    if (want > pl.tiles) want = pl.tiles;
+    if (want < 1) want = 1;
+    if (want > 65535) want = 65535;
+    pl.nsplit = want;
+    return pl;
+}
+
+int supported(const ur_conv_desc* d) {
+    if (!d || d->dtype != UR_BF16) return 0;
+    if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w)) return 0;
+    if (d->cout % BO != 0 || d->cin % BI != 0 || d->in_ld % 8 != 0 || d->out_ld % 8 != 0) return 0;
+    if ((long long)d->n * d->h * d->w >= (1LL << 31)) return 0;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ur_wgrad3x3_tile_supported(const ur_conv_desc* d) { return supported(d); }
+
+size_t ur_wgrad3x3_tile_workspace(const ur_conv_desc* d) {
+    if (!supported(d)) return 0;
+    Plan pl = make_plan(d);
+    return (size_t)pl.nsplit * d->cout * 9 * d->cin * sizeof(float);
+}
+
+int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
+                     ur_stream_t s) {
+    UR_REQUIRE(supported(d), "wgrad3x3_tile: unsupported geometry (needs bf16, 3x3 s1 p1, 64 | cin, 64 | cout)");
+    UR_REQUIRE(x && dy && dw && workspace, "wgrad3x3_tile: null pointer");
+    UR_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "wgrad3x3_tile: tensors must be 16-byte aligned");
+    UR_REQUIRE(ws_bytes >= ur_wgrad3x3_tile_workspace(d), "wgrad3x3_tile: workspace too small");
+    Plan pl = make_plan(d);
+    WgTileParams p{};
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.ws = (float*)workspace;
+    p.N = d->n; p.H = d->h; p.W = d->w; p.Cin = d->cin; p.Cout = d->cout; p.ld_x = d->in_ld; p.ld_dy = d->out_ld;
+    p.tiles_x = ur_cdiv(d->w, TW); p.tiles_y = ur_cdiv(d->h, tile_rows()); p.tiles = pl.tiles;
+    p.ci_blocks = d->cin / BI;
+    if (tile_rows() == 4) hipLaunchKernelGGL((wgrad3x3_tile_kernel<4, 1>), dim3(pl.pairs, pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL((wgrad3x3_tile_kernel<2, 2>), dim3(pl.pairs, pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
+    if (int e = ur_check_launch("wgrad3x3_tile")) return e;
+    const long long per = (long long)d->cout * 9 * d->cin;
+    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3(ur_grid_1d(per, 256)), dim3(256), 0, (hipStream_t)s, p.ws, dw, d->cout,
+                       d->cin, pl.nsplit);
+    return ur_check_launch("wgrad3x3_reduce");
+}
+
+}  // extern "C"

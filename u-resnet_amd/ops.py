@@ -181,10 +181,11 @@ use_tile_kernel = True          # False forces the generic implicit-GEMM kernel 
 
 
 class _Timed:
-    __slots__ = ("tag", "flops", "e0")
+    __slots__ = ("tag", "flops", "e0", "shape")
 
-    def __init__(self, tag, flops):
+    def __init__(self, tag, flops, d=None):
         self.tag, self.flops, self.e0 = tag, flops, None
+        self.shape = None if d is None else (d.n, d.h, d.w, d.cin, d.cout, d.kh, d.stride)
 
     def __enter__(self):
         if kernel_timings is not None:
@@ -196,7 +197,7 @@ class _Timed:
         if self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream())
-            kernel_timings.append((self.tag, self.flops, self.e0, e1))
+            kernel_timings.append((self.tag, self.flops, self.e0, e1, self.shape))
         return False
 
 
@@ -234,14 +235,14 @@ class _Conv2d(Function):
             if want_stats:
                 rows = query("ur_conv3x3_tile_stats_rows", C.byref(d))
                 stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
-            with _Timed("tile_fwd", _conv_flops(d)):
+            with _Timed("tile_fwd", _conv_flops(d), d):
                 call("ur_conv3x3_tile_fwd", x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(stats), C.byref(d), _stream())
         else:
             wp = packs.get(weight, d, _lib.PACK_FWD)
             if want_stats:
                 rows = query("ur_conv2d_stats_rows", C.byref(d))
                 stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
-            with _Timed("igemm_fwd", _conv_flops(d)):
+            with _Timed("igemm_fwd", _conv_flops(d), d):
                 call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
         ctx.save_for_backward(x, weight)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
@@ -260,18 +261,24 @@ class _Conv2d(Function):
             dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
             if use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 1):
                 wp = ctx.packs.get_tile(weight, d, True)
-                with _Timed("tile_dgrad", _conv_flops(d)):
+                with _Timed("tile_dgrad", _conv_flops(d), d):
                     call("ur_conv3x3_tile_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
             else:
                 wp = ctx.packs.get(weight, d, _lib.PACK_DGRAD)
-                with _Timed("igemm_dgrad", _conv_flops(d)):
+                with _Timed("igemm_dgrad", _conv_flops(d), d):
                     call("ur_conv2d_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            ws = _workspace(query("ur_conv2d_wgrad_workspace", C.byref(d)), x.device)
-            with _Timed("wgrad", _conv_flops(d)):
-                call("ur_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
-                     C.byref(d), _stream())
+            if use_tile_kernel and query("ur_wgrad3x3_tile_supported", C.byref(d)):
+                ws = _workspace(query("ur_wgrad3x3_tile_workspace", C.byref(d)), x.device)
+                with _Timed("tile_wgrad", _conv_flops(d), d):
+                    call("ur_wgrad3x3_tile", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                         C.byref(d), _stream())
+            else:
+                ws = _workspace(query("ur_conv2d_wgrad_workspace", C.byref(d)), x.device)
+                with _Timed("wgrad", _conv_flops(d), d):
+                    call("ur_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                         C.byref(d), _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, d.cout, d.cout, x.device)
         return dx, dw, db, None, None, None, None
@@ -293,7 +300,7 @@ class _ConvT2x2(Function):
         d = _desc(x.shape, cout, 2, 2, 2, 0, x.dtype, oh=2 * h, ow=2 * w)
         wp = packs.get(weight, d, _lib.PACK_CONVT_FWD)
         y = empty_nhwc(n, cout, 2 * h, 2 * w, x.dtype, x.device)
-        with _Timed("igemm_fwd", _conv_flops(d, True)):
+        with _Timed("igemm_fwd", _conv_flops(d, True), d):
             call("ur_convT2x2_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), C.byref(d), _stream())
         ctx.save_for_backward(x, weight)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
@@ -308,12 +315,12 @@ class _ConvT2x2(Function):
         if ctx.needs_input_grad[0]:
             wp = ctx.packs.get(weight, d, _lib.PACK_CONVT_DGRAD)
             dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
-            with _Timed("igemm_dgrad", _conv_flops(d, True)):
+            with _Timed("igemm_dgrad", _conv_flops(d, True), d):
                 call("ur_convT2x2_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = _workspace(query("ur_convT2x2_wgrad_workspace", C.byref(d)), x.device)
-            with _Timed("wgrad", _conv_flops(d, True)):
+            with _Timed("wgrad", _conv_flops(d, True), d):
                 call("ur_convT2x2_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
                      C.byref(d), _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
