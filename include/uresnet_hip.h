@@ -139,17 +139,20 @@ int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int 
 /* z = act((y-mean)*invstd*gamma + beta (+ residual));  act: 0 none, 1 relu */
 int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const void* residual, int act, void* z, int dtype, long long rows, int c, ur_stream_t s);
-/* backward pass 1: partial[nparts][c][2] = (sum g, sum g*xhat), g = dz * (z > 0 if act) */
+/* backward pass 1: partial[nparts][c][2] = (sum g, sum g*xhat), g = dz masked by the ReLU (act != 0).
+ * The mask comes from the saved output z when z != NULL, else it is recomputed from y (needs gamma, beta;
+ * valid only when no residual was added before the activation). */
 int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
-                         int act, int dtype, long long rows, int c, float* partial, ur_stream_t s);
+                         const float* gamma, const float* beta, int act, int dtype, long long rows, int c,
+                         float* partial, ur_stream_t s);
 /* sums[c][2] = reduce(partial); dgamma = sums[.,1]; dbeta = sums[.,0]; `partial` is used as scratch */
 int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
                        ur_stream_t s);
 /* backward pass 2: dy = gamma*invstd*(g - sums0/count - xhat*sums1/count); dres = g (optional).
- * eval != 0 treats the statistics as constants: dy = gamma*invstd*g. */
+ * eval != 0 treats the statistics as constants: dy = gamma*invstd*g.  z may be NULL as in pass 1. */
 int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
-                        const float* gamma, const float* sums, int act, int eval, void* dy, void* dres,
-                        int dtype, long long rows, int c, ur_stream_t s);
+                        const float* gamma, const float* beta, const float* sums, int act, int eval, void* dy,
+                        void* dres, int dtype, long long rows, int c, ur_stream_t s);
 
 /* ---------------------------------------------------------------- spatial ops
  * MaxPool2d(2,2) (S/C:105), bilinear Upsample(scale, align_corners=False) (S/C:43,66,362;

@@ -79,19 +79,26 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, lon
     colreduce_body<VEC, 1>(op, rows, C, partial);
 }
 
+// g = dz masked by the ReLU: from the saved output z when given, else recomputed from y
+// ((y-mean)*invstd*gamma + beta > 0 has the sign of the stored activation).
 template <typename T, int VEC>
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                            const T* __restrict__ z, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, int act, long long rows,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int act, long long rows,
                                                            int C, float* __restrict__ partial) {
     auto op = [&](long long r, int col, float* acc) {
         RowVec<T, VEC> g, yy, zz;
         g.load(dz + r * C + col); yy.load(y + r * C + col);
-        if (act) zz.load(z + r * C + col);
+        const bool have_z = act && z != nullptr;
+        if (have_z) zz.load(z + r * C + col);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            float gv = (act && !(zz.v[v] > 0.f)) ? 0.f : g.v[v];
-            float xh = (yy.v[v] - mean[col + v]) * invstd[col + v];
+            const float xh = (yy.v[v] - mean[col + v]) * invstd[col + v];
+            float pre = 1.f;                                   // no activation: always "on"
+            if (have_z) pre = zz.v[v];
+            else if (act) pre = xh * gamma[col + v] + beta[col + v];
+            const float gv = pre > 0.f ? g.v[v] : 0.f;
             acc[v * 2] += gv; acc[v * 2 + 1] += gv * xh;
         }
     };
@@ -225,25 +232,29 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                               const T* __restrict__ z, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                              const float* __restrict__ sums, int act, int eval, float inv_count,
+                                                              const float* __restrict__ beta, const float* __restrict__ sums,
+                                                              int act, int eval, float inv_count,
                                                               T* __restrict__ dy, T* __restrict__ dres, long long total, int C) {
     for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * VEC; i < total;
          i += (long long)gridDim.x * NT * VEC) {
         const int c = (int)(i % C);
         RowVec<T, VEC> g, yy, zz;
         g.load(dz + i); yy.load(y + i);
-        if (act) zz.load(z + i);
+        const bool have_z = act && z != nullptr;
+        if (have_z) zz.load(z + i);
         float o[VEC], gm[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            float gv = (act && !(zz.v[v] > 0.f)) ? 0.f : g.v[v];
+            const float is = invstd[c + v], ga = gamma[c + v];
+            const float xh = (yy.v[v] - mean[c + v]) * is;
+            float pre = 1.f;
+            if (have_z) pre = zz.v[v];
+            else if (act) pre = xh * ga + beta[c + v];
+            const float gv = pre > 0.f ? g.v[v] : 0.f;
             gm[v] = gv;
-            float k = gamma[c + v] * invstd[c + v];
+            const float k = ga * is;
             if (eval) o[v] = k * gv;
-            else {
-                float xh = (yy.v[v] - mean[c + v]) * invstd[c + v];
-                o[v] = k * (gv - sums[(c + v) * 2] * inv_count - xh * sums[(c + v) * 2 + 1] * inv_count);
-            }
+            else o[v] = k * (gv - sums[(c + v) * 2] * inv_count - xh * sums[(c + v) * 2 + 1] * inv_count);
         }
         if constexpr (VEC == 4) {
             ur_store4(dy + i, make_float4(o[0], o[1], o[2], o[3]));
@@ -252,6 +263,50 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
             dy[i] = ur_from_float<T>(o[0]);
             if (dres) dres[i] = ur_from_float<T>(gm[0]);
         }
+    }
+}
+
+// bf16, 8 channels per thread: 16-byte tensor accesses and float4 parameter loads
+__global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
+    const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y, const bf16_t* __restrict__ z, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ sums, int act, int eval, float inv_count, bf16_t* __restrict__ dy, bf16_t* __restrict__ dres,
+    long long total, int C) {
+    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8; i < total; i += (long long)gridDim.x * NT * 8) {
+        const int c = (int)(i % C);
+        const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(dz + i);
+        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
+        bf16x8_t z8 = g8;
+        if (act && z) z8 = *reinterpret_cast<const bf16x8_t*>(z + i);
+        float m[8], is[8], ga[8], be[8], s0[8], s1[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 a = *reinterpret_cast<const float4*>(mean + c + 4 * h), b = *reinterpret_cast<const float4*>(invstd + c + 4 * h);
+            const float4 d = *reinterpret_cast<const float4*>(gamma + c + 4 * h), e = *reinterpret_cast<const float4*>(beta + c + 4 * h);
+            m[4 * h] = a.x; m[4 * h + 1] = a.y; m[4 * h + 2] = a.z; m[4 * h + 3] = a.w;
+            is[4 * h] = b.x; is[4 * h + 1] = b.y; is[4 * h + 2] = b.z; is[4 * h + 3] = b.w;
+            ga[4 * h] = d.x; ga[4 * h + 1] = d.y; ga[4 * h + 2] = d.z; ga[4 * h + 3] = d.w;
+            be[4 * h] = e.x; be[4 * h + 1] = e.y; be[4 * h + 2] = e.z; be[4 * h + 3] = e.w;
+            if (!eval) {
+                const float4 p = *reinterpret_cast<const float4*>(sums + (c + 4 * h) * 2), q = *reinterpret_cast<const float4*>(sums + (c + 4 * h) * 2 + 4);
+                s0[4 * h] = p.x; s1[4 * h] = p.y; s0[4 * h + 1] = p.z; s1[4 * h + 1] = p.w;
+                s0[4 * h + 2] = q.x; s1[4 * h + 2] = q.y; s0[4 * h + 3] = q.z; s1[4 * h + 3] = q.w;
+            }
+        }
+        bf16x8_t o8, r8;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const float xh = ((float)y8[v] - m[v]) * is[v];
+            float pre = 1.f;
+            if (act && z) pre = (float)z8[v];
+            else if (act) pre = xh * ga[v] + be[v];
+            const float gv = pre > 0.f ? (float)g8[v] : 0.f;
+            const float k = ga[v] * is[v];
+            const float o = eval ? k * gv : k * (gv - s0[v] * inv_count - xh * s1[v] * inv_count);
+            o8[v] = (bf16_t)o; r8[v] = (bf16_t)gv;
+        }
+        *reinterpret_cast<bf16x8_t*>(dy + i) = o8;
+        if (dres) *reinterpret_cast<bf16x8_t*>(dres + i) = r8;
     }
 }
 
@@ -342,17 +397,18 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
     return ur_check_launch("bn_act_fwd");
 }
 
-int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd, int act,
-                         int dtype, long long rows, int c, float* partial, ur_stream_t s) {
+int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, int act, int dtype, long long rows, int c, float* partial,
+                         ur_stream_t s) {
     UR_REQUIRE(dz && y && mean && invstd && partial && rows > 0 && c > 0, "bn_act_bwd_reduce: bad arguments");
-    UR_REQUIRE(!act || z, "bn_act_bwd_reduce: activation mask needs z");
+    UR_REQUIRE(!act || z || (gamma && beta), "bn_act_bwd_reduce: the activation mask needs z or (gamma, beta)");
     const bool vec = (c % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(z);
     const int grid = reduce_grid(rows, c, c % 4 == 0 ? 4 : 1);
     UR_DISPATCH_DTYPE(dtype, {
         if (vec) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
-                                    (const T*)y, (const T*)z, mean, invstd, act, rows, c, partial);
+                                    (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, partial);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
-                                (const T*)y, (const T*)z, mean, invstd, act, rows, c, partial);
+                                (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, partial);
     });
     return ur_check_launch("bn_act_bwd_reduce");
 }
@@ -368,21 +424,29 @@ int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dg
 }
 
 int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
-                        const float* gamma, const float* sums, int act, int eval, void* dy, void* dres, int dtype,
-                        long long rows, int c, ur_stream_t s) {
+                        const float* gamma, const float* beta, const float* sums, int act, int eval, void* dy, void* dres,
+                        int dtype, long long rows, int c, ur_stream_t s) {
     UR_REQUIRE(dz && y && mean && invstd && gamma && dy && rows > 0 && c > 0, "bn_act_bwd_apply: bad arguments");
-    UR_REQUIRE(!act || z, "bn_act_bwd_apply: activation mask needs z");
+    UR_REQUIRE(!act || z || beta, "bn_act_bwd_apply: the activation mask needs z or beta");
     UR_REQUIRE(eval || sums, "bn_act_bwd_apply: training mode needs the reduced sums");
     const long long total = rows * c;
     const float inv_count = 1.f / (float)rows;
-    const bool vec = (c % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(z) && aligned16(dy) && aligned16(dres);
+    const bool al = aligned16(dz) && aligned16(y) && aligned16(z) && aligned16(dy) && aligned16(dres);
+    if (dtype == UR_BF16 && c % 8 == 0 && al && beta && aligned16(mean) && aligned16(invstd) && aligned16(gamma) &&
+        aligned16(beta) && aligned16(sums)) {
+        hipLaunchKernelGGL(bn_act_bwd_apply_bf16x8_kernel, dim3(ur_grid_1d(total / 8, NT)), dim3(NT), 0, (hipStream_t)s,
+                           (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, mean, invstd, gamma, beta, sums, act, eval,
+                           inv_count, (bf16_t*)dy, (bf16_t*)dres, total, c);
+        return ur_check_launch("bn_act_bwd_apply");
+    }
+    const bool vec = (c % 4 == 0) && al;
     UR_DISPATCH_DTYPE(dtype, {
         if (vec) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 4>), dim3(ur_grid_1d(total / 4, NT)), dim3(NT), 0,
-                                    (hipStream_t)s, (const T*)dz, (const T*)y, (const T*)z, mean, invstd, gamma, sums, act,
-                                    eval, inv_count, (T*)dy, (T*)dres, total, c);
+                                    (hipStream_t)s, (const T*)dz, (const T*)y, (const T*)z, mean, invstd, gamma, beta, sums,
+                                    act, eval, inv_count, (T*)dy, (T*)dres, total, c);
         else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 1>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0, (hipStream_t)s,
-                                (const T*)dz, (const T*)y, (const T*)z, mean, invstd, gamma, sums, act, eval, inv_count,
-                                (T*)dy, (T*)dres, total, c);
+                                (const T*)dz, (const T*)y, (const T*)z, mean, invstd, gamma, beta, sums, act, eval,
+                                inv_count, (T*)dy, (T*)dres, total, c);
     });
     return ur_check_launch("bn_act_bwd_apply");
 }

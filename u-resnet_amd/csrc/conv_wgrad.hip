@@ -195,18 +195,27 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
         }
 }
 
-// dw[o][i][tap] = sum_s ws[s][o][tap*I + i]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int O, int I, int taps,
-                                    int nsplit) {
+// dw[o][i][tap] = sum_s ws[s][o][tap*I + i].  32 outputs x 8 split lanes per workgroup: the slab reads of a
+// wave are 128-byte rows and the split loop is 8-way parallel (long split lists come with small outputs).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int O, int I,
+                                                           int taps, int nsplit) {
+    __shared__ float red[8][32];
     const long long per = (long long)O * I * taps;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < per;
-         idx += (long long)gridDim.x * blockDim.x) {
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long long idx = blockIdx.x * 32LL + ol;
+    float s = 0.f;
+    if (idx < per)
+        for (int k = sl; k < nsplit; k += 8) s += ws[(long long)k * per + idx];
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && idx < per) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][ol];
         int o = (int)(idx / ((long long)I * taps));
         int rem = (int)(idx - (long long)o * I * taps);
-        int tap = rem / I, i = rem - tap * I;           // read order: (tap, i) contiguous
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * per + idx];
-        dw[((long long)o * I + i) * taps + tap] = s;
+        int tap = rem / I, i = rem - tap * I;           // slab order: (tap, i) contiguous
+        dw[((long long)o * I + i) * taps + tap] = t;
     }
 }
 
@@ -247,7 +256,7 @@ int launch_wgrad(WgradParams& p, float* dw, hipStream_t st) {
     else hipLaunchKernelGGL((conv_wgrad_kernel<T, 1, 1>), grid, dim3(NTHREADS), 0, st, p);
     if (int e = ur_check_launch("conv_wgrad")) return e;
     const long long per = (long long)p.O * p.Kred;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ur_grid_1d(per, 256)), dim3(256), 0, st, p.ws, dw, p.O, p.I,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, p.ws, dw, p.O, p.I,
                        p.kh * p.kw, pl.nsplit);
     return ur_check_launch("wgrad_reduce");
 }

@@ -159,16 +159,26 @@ __global__ __launch_bounds__(NTHREADS, MINW) void wgrad3x3_tile_kernel(WgTilePar
         }
 }
 
-// dw[co][ci][tap] = sum_s ws[s][co][tap][ci]
-__global__ void wgrad3x3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int nsplit) {
+// dw[co][ci][tap] = sum_s ws[s][co][tap][ci]; 32 outputs x 8 split lanes per workgroup
+__global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout,
+                                                              int Cin, int nsplit) {
+    __shared__ float red[8][32];
     const long long per = (long long)Cout * 9 * Cin;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < per; idx += (long long)gridDim.x * blockDim.x) {
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long long idx = blockIdx.x * 32LL + ol;
+    float s = 0.f;
+    if (idx < per)
+        for (int k = sl; k < nsplit; k += 8) s += ws[(long long)k * per + idx];
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && idx < per) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][ol];
         const int ci = (int)(idx % Cin);
-        const long long t = idx / Cin;
-        const int tap = (int)(t % 9), co = (int)(t / 9);
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * per + idx];
-        dw[((long long)co * Cin + ci) * 9 + tap] = s;
+        const long long q = idx / Cin;
+        const int tap = (int)(q % 9), co = (int)(q / 9);
+        dw[((long long)co * Cin + ci) * 9 + tap] = t;
     }
 }
 
@@ -229,8 +239,8 @@ int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, 
     else hipLaunchKernelGGL((wgrad3x3_tile_kernel<2, 2>), dim3(pl.pairs, pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
     if (int e = ur_check_launch("wgrad3x3_tile")) return e;
     const long long per = (long long)d->cout * 9 * d->cin;
-    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3(ur_grid_1d(per, 256)), dim3(256), 0, (hipStream_t)s, p.ws, dw, d->cout,
-                       d->cin, pl.nsplit);
+    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, (hipStream_t)s, p.ws, dw,
+                       d->cout, d->cin, pl.nsplit);
     return ur_check_launch("wgrad3x3_reduce");
 }
 

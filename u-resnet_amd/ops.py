@@ -394,21 +394,22 @@ class _BNAct(Function):
         z = torch.empty_like(y, memory_format=CL)
         call("ur_bn_act_fwd", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
              _p(residual), act, z.data_ptr(), _dt(y), rows, c, _stream())
-        ctx.save_for_backward(y, z if act else None, gamma, mean, invstd)
+        # the ReLU mask is recomputed from y in backward unless a residual was added before the activation
+        ctx.save_for_backward(y, z if (act and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.act, ctx.eval, ctx.has_res = act, not training, residual is not None
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        y, z, gamma, mean, invstd = ctx.saved_tensors
+        y, z, gamma, beta, mean, invstd = ctx.saved_tensors
         n, c, h, w = y.shape
         rows = n * h * w
         dev = y.device
         dz = _g(dz)
         nparts = query("ur_bn_stats_rows", rows, c)
         partial = torch.empty((nparts, c, 2), dtype=torch.float32, device=dev)
-        call("ur_bn_act_bwd_reduce", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(), ctx.act,
-             _dt(y), rows, c, partial.data_ptr(), _stream())
+        call("ur_bn_act_bwd_reduce", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
+             gamma.data_ptr(), beta.data_ptr(), ctx.act, _dt(y), rows, c, partial.data_ptr(), _stream())
         sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
@@ -417,8 +418,8 @@ class _BNAct(Function):
         dy = torch.empty_like(y, memory_format=CL)
         dres = torch.empty_like(y, memory_format=CL) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
-             gamma.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres), _dt(y), rows, c,
-             _stream())
+             gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres), _dt(y),
+             rows, c, _stream())
         return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
