@@ -80,24 +80,35 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, lon
 }
 
 // g = dz masked by the ReLU: from the saved output z when given, else recomputed from y
-// ((y-mean)*invstd*gamma + beta > 0 has the sign of the stored activation).
+// ((y-mean)*invstd*gamma + beta > 0 has the sign of the stored activation).  A thread keeps one channel
+// group for its whole row walk, so the per-channel constants live in registers.
 template <typename T, int VEC>
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                            const T* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int act, long long rows,
                                                            int C, float* __restrict__ partial) {
+    const bool have_z = act && z != nullptr;
+    const bool recompute = act && z == nullptr;
+    int cached_col = -1;
+    float m[VEC], is[VEC], ga[VEC], be[VEC];
     auto op = [&](long long r, int col, float* acc) {
+        if (col != cached_col) {
+            cached_col = col;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                m[v] = mean[col + v]; is[v] = invstd[col + v];
+                ga[v] = recompute ? gamma[col + v] : 0.f; be[v] = recompute ? beta[col + v] : 1.f;
+            }
+        }
         RowVec<T, VEC> g, yy, zz;
         g.load(dz + r * C + col); yy.load(y + r * C + col);
-        const bool have_z = act && z != nullptr;
         if (have_z) zz.load(z + r * C + col);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const float xh = (yy.v[v] - mean[col + v]) * invstd[col + v];
-            float pre = 1.f;                                   // no activation: always "on"
+            const float xh = (yy.v[v] - m[v]) * is[v];
+            float pre = xh * ga[v] + be[v];                    // no activation: 0 * xh + 1 > 0
             if (have_z) pre = zz.v[v];
-            else if (act) pre = xh * gamma[col + v] + beta[col + v];
             const float gv = pre > 0.f ? g.v[v] : 0.f;
             acc[v * 2] += gv; acc[v * 2 + 1] += gv * xh;
         }
@@ -199,8 +210,12 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ y,
                                                         const float* __restrict__ beta, const T* __restrict__ res, int act,
                                                         T* __restrict__ z, long long total, int C) {
     // C % 4 == 0 (checked on the host): a float4 / bf16x4 never straddles a row
-    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * NT * 4) {
-        const int c = (int)(i % C);
+    const long long stride = (long long)gridDim.x * NT * 4;
+    const int cstep = (int)(stride % C);          // channel offset advances mod C: no 64-bit division in the loop
+    int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 4) % C);
+    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 4; i < total; i += stride) {
+        const int c = cnext;
+        cnext += cstep; if (cnext >= C) cnext -= C;
         float4 v = ur_load4(y + i);
         float4 m = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
         float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
@@ -210,6 +225,42 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ y,
         if (res) { float4 r = ur_load4(res + i); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         if (act) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         ur_store4(z + i, o);
+    }
+}
+
+// bf16, 8 channels per thread (16-byte accesses); scale/shift folded per channel: z = act(y*a + b (+res))
+__global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const bf16_t* __restrict__ res,
+                                                               int act, bf16_t* __restrict__ z, long long total, int C) {
+    const long long stride = (long long)gridDim.x * NT * 8;
+    const int cstep = (int)(stride % C);
+    int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 8) % C);
+    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8; i < total; i += stride) {
+        const int c = cnext;
+        cnext += cstep; if (cnext >= C) cnext -= C;
+        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
+        bf16x8_t r8 = y8;
+        if (res) r8 = *reinterpret_cast<const bf16x8_t*>(res + i);
+        float m[8], is[8], ga[8], be[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 a = *reinterpret_cast<const float4*>(mean + c + 4 * h), b = *reinterpret_cast<const float4*>(invstd + c + 4 * h);
+            const float4 d = *reinterpret_cast<const float4*>(gamma + c + 4 * h), e = *reinterpret_cast<const float4*>(beta + c + 4 * h);
+            m[4 * h] = a.x; m[4 * h + 1] = a.y; m[4 * h + 2] = a.z; m[4 * h + 3] = a.w;
+            is[4 * h] = b.x; is[4 * h + 1] = b.y; is[4 * h + 2] = b.z; is[4 * h + 3] = b.w;
+            ga[4 * h] = d.x; ga[4 * h + 1] = d.y; ga[4 * h + 2] = d.z; ga[4 * h + 3] = d.w;
+            be[4 * h] = e.x; be[4 * h + 1] = e.y; be[4 * h + 2] = e.z; be[4 * h + 3] = e.w;
+        }
+        bf16x8_t o8;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            float o = ((float)y8[v] - m[v]) * is[v] * ga[v] + be[v];      // same operation order as the 4-wide kernel
+            if (res) o += (float)r8[v];
+            if (act) o = fmaxf(o, 0.f);
+            o8[v] = (bf16_t)o;
+        }
+        *reinterpret_cast<bf16x8_t*>(z + i) = o8;
     }
 }
 
@@ -235,9 +286,12 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
                                                               const float* __restrict__ beta, const float* __restrict__ sums,
                                                               int act, int eval, float inv_count,
                                                               T* __restrict__ dy, T* __restrict__ dres, long long total, int C) {
-    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * VEC; i < total;
-         i += (long long)gridDim.x * NT * VEC) {
-        const int c = (int)(i % C);
+    const long long stride = (long long)gridDim.x * NT * VEC;
+    const int cstep = (int)(stride % C);          // channel offset advances mod C: no 64-bit division in the loop
+    int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * VEC) % C);
+    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * VEC; i < total; i += stride) {
+        const int c = cnext;
+        cnext += cstep; if (cnext >= C) cnext -= C;
         RowVec<T, VEC> g, yy, zz;
         g.load(dz + i); yy.load(y + i);
         const bool have_z = act && z != nullptr;
@@ -272,8 +326,12 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ sums, int act, int eval, float inv_count, bf16_t* __restrict__ dy, bf16_t* __restrict__ dres,
     long long total, int C) {
-    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8; i < total; i += (long long)gridDim.x * NT * 8) {
-        const int c = (int)(i % C);
+    const long long stride = (long long)gridDim.x * NT * 8;
+    const int cstep = (int)(stride % C);          // channel offset advances mod C: no 64-bit division in the loop
+    int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 8) % C);
+    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8; i < total; i += stride) {
+        const int c = cnext;
+        cnext += cstep; if (cnext >= C) cnext -= C;
         const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(dz + i);
         const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
         bf16x8_t z8 = g8;
@@ -388,6 +446,11 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
     const long long total = rows * c;
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(z) && aligned16(residual) && aligned16(mean) &&
                      aligned16(invstd) && aligned16(gamma) && aligned16(beta);
+    if (dtype == UR_BF16 && vec && c % 8 == 0) {
+        hipLaunchKernelGGL(bn_act_fwd_bf16x8_kernel, dim3(ur_grid_1d(total / 8, NT)), dim3(NT), 0, (hipStream_t)s,
+                           (const bf16_t*)y, mean, invstd, gamma, beta, (const bf16_t*)residual, act, (bf16_t*)z, total, c);
+        return ur_check_launch("bn_act_fwd");
+    }
     UR_DISPATCH_DTYPE(dtype, {
         if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(ur_grid_1d(total / 4, NT)), dim3(NT), 0, (hipStream_t)s,
                                     (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c);

@@ -75,11 +75,12 @@ __global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__
                 for (int b = 0; b < 4; ++b) wr[tap][a * 4 + b] = DGRAD ? wq[(b * 4 + a) * 9 + tap] : wq[(a * 4 + b) * 9 + tap];
         }
     }
-    const long long P = (long long)N * H * W;
-    for (long long pix = (long long)blockIdx.x * PS + pslot; pix < P; pix += (long long)gridDim.x * PS) {
-        const int x = (int)(pix % W);
-        const long long t = pix / W;
-        const int y = (int)(t % H), n = (int)(t / H);
+    const int P = N * H * W;                     // < 2^31 (checked on the host): 32-bit index arithmetic
+    for (int pix = blockIdx.x * PS + pslot; pix < P; pix += gridDim.x * PS) {
+        const int t = pix / W;
+        const int x = pix - t * W;
+        const int n = t / H;
+        const int y = t - n * H;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__
             for (int kx = 0; kx < 3; ++kx) {
                 const int xx = DGRAD ? x + 1 - kx : x + kx - 1;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (yok && (unsigned)xx < (unsigned)W) v = ur_load4(in + (((long long)n * H + yy) * W + xx) * C + q * 4);
+                if (yok && (unsigned)xx < (unsigned)W) v = ur_load4(in + ((size_t)((n * H + yy) * W + xx)) * C + q * 4);
                 const float vi[4] = {v.x, v.y, v.z, v.w};
                 const int tap = ky * 3 + kx;
                 if constexpr (CPG == 1) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__
                 }
             }
         }
-        ur_store4(out + pix * C + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        ur_store4(out + (size_t)pix * C + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
 
@@ -146,11 +147,12 @@ __global__ __launch_bounds__(NT) void gconv3x3_wgrad_kernel(const T* __restrict_
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[t][v] = 0.f;
         if (slot < slots && q < Q) {
-            for (long long pix = (long long)blockIdx.x * slots + slot; pix < P; pix += (long long)gridDim.x * slots) {
-                const int xx0 = (int)(pix % W);
-                const long long t = pix / W;
-                const int yy0 = (int)(t % H), n = (int)(t / H);
-                const float4 g4 = ur_load4(dy + pix * C + q * 4);
+            for (int pix = blockIdx.x * slots + slot; pix < (int)P; pix += gridDim.x * slots) {
+                const int t = pix / W;
+                const int xx0 = pix - t * W;
+                const int n = t / H;
+                const int yy0 = t - n * H;
+                const float4 g4 = ur_load4(dy + (size_t)pix * C + q * 4);
                 const float g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(NT) void gconv3x3_wgrad_kernel(const T* __restrict_
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = xx0 + kx - 1;
                         if ((unsigned)xx >= (unsigned)W) continue;
-                        const float4 v4 = ur_load4(x + (((long long)n * H + yy) * W + xx) * C + q * 4);
+                        const float4 v4 = ur_load4(x + ((size_t)((n * H + yy) * W + xx)) * C + q * 4);
                         const float vi[4] = {v4.x, v4.y, v4.z, v4.w};
                         if constexpr (CPG == 1) {
 #pragma unroll
@@ -195,12 +197,22 @@ __global__ __launch_bounds__(NT) void gconv3x3_wgrad_kernel(const T* __restrict_
     }
 }
 
-__global__ void gconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, long long wsz,
-                                          float* __restrict__ dw) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < wsz; i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < nparts; ++p) s += partial[(long long)p * wsz + i];
-        dw[i] = s;
+// dw[i] = sum_p partial[p][i]; 32 outputs x 8 partial lanes per workgroup, fixed summation order
+__global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, long long wsz,
+                                                                 float* __restrict__ dw) {
+    __shared__ float red[8][32];
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long long i = blockIdx.x * 32LL + ol;
+    float s = 0.f;
+    if (i < wsz)
+        for (int p = sl; p < nparts; p += 8) s += partial[(long long)p * wsz + i];
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < wsz) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][ol];
+        dw[i] = t;
     }
 }
 
@@ -217,6 +229,7 @@ int wgrad_blocks(long long P, int C) {
 int check_args(const void* a, const void* b, const void* c, int dtype, int n, int h, int w, int ch, int cpg) {
     UR_REQUIRE(a && b && c, "gconv3x3: null pointer");
     UR_REQUIRE(n > 0 && h > 0 && w > 0 && ch > 0, "gconv3x3: non-positive dimension");
+    UR_REQUIRE((long long)n * h * w < (1LL << 31), "gconv3x3: more than 2^31 pixels");
     UR_REQUIRE(cpg == 1 || cpg == 4, "gconv3x3: channels per group must be 1 or 4 (got %d)", cpg);
     UR_REQUIRE(ch % 4 == 0, "gconv3x3: channel count %d is not a multiple of 4", ch);
     const int es = dtype == UR_BF16 ? 2 : 4;
@@ -256,7 +269,7 @@ int ur_gconv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace,
     });
     if (int e = ur_check_launch("gconv3x3_wgrad")) return e;
     const long long wsz = (long long)c * cpg * 9;
-    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3(ur_grid_1d(wsz, 256)), dim3(256), 0, (hipStream_t)s, partial, grid, wsz, dw);
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((unsigned)((wsz + 31) / 32)), dim3(256), 0, (hipStream_t)s, partial, grid, wsz, dw);
     return ur_check_launch("gconv3x3_wgrad_reduce");
 }
 

@@ -25,20 +25,21 @@ template <typename T, int V> struct Pack {
     }
 };
 
+// 64-bit division costs ~100 instructions on the GPU: index arithmetic is 32-bit (hosts check totals < 2^31)
 #define GRID_STRIDE(i, total) \
-    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < (total); i += (long long)gridDim.x * NT)
+    for (unsigned i = blockIdx.x * (unsigned)NT + threadIdx.x; i < (unsigned)(total); i += gridDim.x * (unsigned)NT)
 
 // ------------------------------------------------------------------ max pool 2x2 stride 2
 template <typename T, int V>
 __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          uint8_t* __restrict__ idx, int N, int H, int W, int C) {
     const int OH = H / 2, OW = W / 2, CV = C / V;
-    const long long total = (long long)N * OH * OW * CV;
+    const unsigned total = (unsigned)N * OH * OW * CV;
     GRID_STRIDE(i, total) {
         int cv = (int)(i % CV);
-        long long pix = i / CV;
+        unsigned pix = i / CV;
         int ox = (int)(pix % OW);
-        long long t = pix / OW;
+        unsigned t = pix / OW;
         int oy = (int)(t % OH), n = (int)(t / OH);
         const T* base = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * C + cv * V;
         Pack<T, V> a, b, c, d, o;
@@ -53,9 +54,9 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
             if (d.v[k] > m || d.v[k] != d.v[k]) { m = d.v[k]; s = 3; }
             o.v[k] = m; sel[k] = (uint8_t)s;
         }
-        o.store(y + pix * C + cv * V);
+        o.store(y + (size_t)pix * C + cv * V);
 #pragma unroll
-        for (int k = 0; k < V; ++k) idx[pix * C + cv * V + k] = sel[k];
+        for (int k = 0; k < V; ++k) idx[(size_t)pix * C + cv * V + k] = sel[k];
     }
 }
 
@@ -63,12 +64,12 @@ template <typename T, int V>
 __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                          T* __restrict__ dx, int N, int H, int W, int C) {
     const int OH = H / 2, OW = W / 2, CV = C / V;
-    const long long total = (long long)N * H * W * CV;
+    const unsigned total = (unsigned)N * H * W * CV;
     GRID_STRIDE(i, total) {
         int cv = (int)(i % CV);
-        long long pix = i / CV;
+        unsigned pix = i / CV;
         int ix = (int)(pix % W);
-        long long t = pix / W;
+        unsigned t = pix / W;
         int iy = (int)(t % H), n = (int)(t / H);
         int oy = iy >> 1, ox = ix >> 1;
         Pack<T, V> o; o.fill(0.f);
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ d
 #pragma unroll
             for (int k = 0; k < V; ++k) o.v[k] = idx[op + k] == me ? g.v[k] : 0.f;
         }
-        o.store(dx + pix * C + cv * V);
+        o.store(dx + (size_t)pix * C + cv * V);
     }
 }
 
@@ -98,12 +99,12 @@ template <typename T, int V>
 __global__ __launch_bounds__(NT) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
                                                           int C, int scale, float rscale) {
     const int OH = H * scale, OW = W * scale, CV = C / V;
-    const long long total = (long long)N * OH * OW * CV;
+    const unsigned total = (unsigned)N * OH * OW * CV;
     GRID_STRIDE(i, total) {
         int cv = (int)(i % CV);
-        long long pix = i / CV;
+        unsigned pix = i / CV;
         int ox = (int)(pix % OW);
-        long long t = pix / OW;
+        unsigned t = pix / OW;
         int oy = (int)(t % OH), n = (int)(t / OH);
         int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
         bilin_src(oy, rscale, H, y0, y1, ly0, ly1);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(NT) void upsample_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int k = 0; k < V; ++k)
             o.v[k] = ly0 * (lx0 * v00.v[k] + lx1 * v01.v[k]) + ly1 * (lx0 * v10.v[k] + lx1 * v11.v[k]);
-        o.store(y + pix * C + cv * V);
+        o.store(y + (size_t)pix * C + cv * V);
     }
 }
 
@@ -124,12 +125,12 @@ template <typename T, int V>
 __global__ __launch_bounds__(NT) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
                                                           int C, int scale, float rscale) {
     const int OH = H * scale, OW = W * scale, CV = C / V;
-    const long long total = (long long)N * H * W * CV;
+    const unsigned total = (unsigned)N * H * W * CV;
     GRID_STRIDE(i, total) {
         int cv = (int)(i % CV);
-        long long pix = i / CV;
+        unsigned pix = i / CV;
         int ix = (int)(pix % W);
-        long long t = pix / W;
+        unsigned t = pix / W;
         int iy = (int)(t % H), n = (int)(t / H);
         float acc[V];
 #pragma unroll
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(NT) void upsample_bwd_kernel(const T* __restrict__ 
         Pack<T, V> o;
 #pragma unroll
         for (int k = 0; k < V; ++k) o.v[k] = acc[k];
-        o.store(dx + pix * C + cv * V);
+        o.store(dx + (size_t)pix * C + cv * V);
     }
 }
 
@@ -163,13 +164,13 @@ template <typename T>
 __global__ __launch_bounds__(NT) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
                                                          int C, int k) {
     const int OH = H / k, OW = W / k;
-    const long long total = (long long)N * OH * OW * C;
+    const unsigned total = (unsigned)N * OH * OW * C;
     const float inv = 1.f / (float)(k * k);
     GRID_STRIDE(i, total) {
         int c = (int)(i % C);
-        long long pix = i / C;
+        unsigned pix = i / C;
         int ox = (int)(pix % OW);
-        long long t = pix / OW;
+        unsigned t = pix / OW;
         int oy = (int)(t % OH), n = (int)(t / OH);
         float s = 0.f;
         for (int dy = 0; dy < k; ++dy)
@@ -183,13 +184,13 @@ template <typename T>
 __global__ __launch_bounds__(NT) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
                                                          int C, int k) {
     const int OH = H / k, OW = W / k;
-    const long long total = (long long)N * H * W * C;
+    const unsigned total = (unsigned)N * H * W * C;
     const float inv = 1.f / (float)(k * k);
     GRID_STRIDE(i, total) {
         int c = (int)(i % C);
-        long long pix = i / C;
+        unsigned pix = i / C;
         int ix = (int)(pix % W);
-        long long t = pix / W;
+        unsigned t = pix / W;
         int iy = (int)(t % H), n = (int)(t / H);
         int oy = iy / k, ox = ix / k;
         float v = 0.f;
@@ -204,18 +205,18 @@ __global__ __launch_bounds__(NT) void copy_channels_kernel(const T* __restrict__
                                                            T* __restrict__ dst, int dst_ld, int dh, int dw, int pad_t,
                                                            int pad_l, int N, int C) {
     const int CV = C / V;
-    const long long total = (long long)N * dh * dw * CV;
+    const unsigned total = (unsigned)N * dh * dw * CV;
     GRID_STRIDE(i, total) {
         int cv = (int)(i % CV);
-        long long pix = i / CV;
+        unsigned pix = i / CV;
         int x = (int)(pix % dw);
-        long long t = pix / dw;
+        unsigned t = pix / dw;
         int y = (int)(t % dh), n = (int)(t / dh);
         int sy = y - pad_t, sx = x - pad_l;
         Pack<T, V> o; o.fill(0.f);
         if ((unsigned)sy < (unsigned)sh && (unsigned)sx < (unsigned)sw)
             o.load(src + (((long long)n * sh + sy) * sw + sx) * src_ld + cv * V);
-        o.store(dst + pix * dst_ld + cv * V);
+        o.store(dst + (size_t)pix * dst_ld + cv * V);
     }
 }
 
@@ -226,9 +227,9 @@ __global__ __launch_bounds__(NT) void channel_shuffle_kernel(const T* __restrict
     const long long total = rows * C;
     GRID_STRIDE(i, total) {
         int co = (int)(i % C);
-        long long r = i / C;
+        unsigned r = i / C;
         int j = co / groups, g = co - j * groups;      // out channel j*groups + g  <-  in channel g*cpg + j
-        y[i] = x[r * C + g * cpg + j];
+        y[i] = x[(size_t)r * C + g * cpg + j];
     }
 }
 
@@ -236,8 +237,8 @@ template <typename T>
 __global__ __launch_bounds__(NT) void add_inplace_kernel(T* __restrict__ a, const T* __restrict__ b, long long count) {
     const long long n4 = count / 4;
     GRID_STRIDE(i, n4) {
-        float4 u = ur_load4(a + i * 4), v = ur_load4(b + i * 4);
-        ur_store4(a + i * 4, make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
+        float4 u = ur_load4(a + (size_t)i * 4), v = ur_load4(b + (size_t)i * 4);
+        ur_store4(a + (size_t)i * 4, make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
     }
     if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
         long long i = n4 * 4 + threadIdx.x;
@@ -321,6 +322,7 @@ int transpose_dispatch(const void* src, int sdt, void* dst, int ddt, int B, int 
 }
 
 bool al(const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; }
+#define UR_REQUIRE_32BIT(total, what) UR_REQUIRE((long long)(total) < (1LL << 31), what ": more than 2^31 elements")
 int esize(int dtype) { return dtype == UR_BF16 ? 2 : 4; }
 
 }  // namespace
@@ -337,6 +339,7 @@ int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, in
     UR_REQUIRE(x && y && idx && n > 0 && h >= 2 && w >= 2 && c > 0, "maxpool_fwd: bad arguments");
     const bool vec = c % 4 == 0 && al(x, 4 * esize(dtype)) && al(y, 4 * esize(dtype));
     const long long total = (long long)n * (h / 2) * (w / 2) * c;
+    UR_REQUIRE_32BIT(total, "maxpool_fwd");
     SPATIAL_LAUNCH(maxpool_fwd_kernel, total, (const T*)x, (T*)y, idx, n, h, w, c);
     return ur_check_launch("maxpool_fwd");
 }
@@ -345,6 +348,7 @@ int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, i
     UR_REQUIRE(dy && dx && idx && n > 0 && h >= 2 && w >= 2 && c > 0, "maxpool_bwd: bad arguments");
     const bool vec = c % 4 == 0 && al(dy, 4 * esize(dtype)) && al(dx, 4 * esize(dtype));
     const long long total = (long long)n * h * w * c;
+    UR_REQUIRE_32BIT(total, "maxpool_bwd");
     SPATIAL_LAUNCH(maxpool_bwd_kernel, total, (const T*)dy, idx, (T*)dx, n, h, w, c);
     return ur_check_launch("maxpool_bwd");
 }
@@ -353,6 +357,7 @@ int ur_upsample_bilinear_fwd(const void* x, void* y, int dtype, int n, int h, in
     UR_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && scale >= 1, "upsample_fwd: bad arguments");
     const bool vec = c % 4 == 0 && al(x, 4 * esize(dtype)) && al(y, 4 * esize(dtype));
     const long long total = (long long)n * h * scale * w * scale * c;
+    UR_REQUIRE_32BIT(total, "upsample_fwd");
     const float rscale = (float)(1.0 / (double)scale);
     SPATIAL_LAUNCH(upsample_fwd_kernel, total, (const T*)x, (T*)y, n, h, w, c, scale, rscale);
     return ur_check_launch("upsample_fwd");
@@ -362,6 +367,7 @@ int ur_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int n, int h, 
     UR_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && scale >= 1, "upsample_bwd: bad arguments");
     const bool vec = c % 4 == 0 && al(dy, 4 * esize(dtype)) && al(dx, 4 * esize(dtype));
     const long long total = (long long)n * h * w * c;
+    UR_REQUIRE_32BIT(total, "upsample_bwd");
     const float rscale = (float)(1.0 / (double)scale);
     SPATIAL_LAUNCH(upsample_bwd_kernel, total, (const T*)dy, (T*)dx, n, h, w, c, scale, rscale);
     return ur_check_launch("upsample_bwd");
@@ -370,6 +376,7 @@ int ur_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int n, int h, 
 int ur_avgpool_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c, int k, ur_stream_t s) {
     UR_REQUIRE(x && y && n > 0 && k > 0 && h >= k && w >= k && c > 0, "avgpool_fwd: bad arguments");
     const long long total = (long long)n * (h / k) * (w / k) * c;
+    UR_REQUIRE_32BIT(total, "avgpool_fwd");
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0,
                                                 (hipStream_t)s, (const T*)x, (T*)y, n, h, w, c, k));
     return ur_check_launch("avgpool_fwd");
@@ -378,6 +385,7 @@ int ur_avgpool_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c
 int ur_avgpool_bwd(const void* dy, void* dx, int dtype, int n, int h, int w, int c, int k, ur_stream_t s) {
     UR_REQUIRE(dy && dx && n > 0 && k > 0 && h >= k && w >= k && c > 0, "avgpool_bwd: bad arguments");
     const long long total = (long long)n * h * w * c;
+    UR_REQUIRE_32BIT(total, "avgpool_bwd");
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0,
                                                 (hipStream_t)s, (const T*)dy, (T*)dx, n, h, w, c, k));
     return ur_check_launch("avgpool_bwd");
@@ -393,6 +401,7 @@ int ur_copy_channels(const void* src, int src_ld, int src_coff, int sh, int sw, 
     char* dp = (char*)dst + (size_t)dst_coff * es;
     const bool vec = c % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0 && al(sp, 4 * es) && al(dp, 4 * es);
     const long long total = (long long)n * dh * dw * c;
+    UR_REQUIRE_32BIT(total, "copy_channels");
     SPATIAL_LAUNCH(copy_channels_kernel, total, (const T*)sp, src_ld, sh, sw, (T*)dp, dst_ld, dh, dw, pad_t, pad_l, n, c);
     return ur_check_launch("copy_channels");
 }
@@ -400,6 +409,7 @@ int ur_copy_channels(const void* src, int src_ld, int src_coff, int sh, int sw, 
 int ur_channel_shuffle(const void* x, void* y, int dtype, long long rows, int c, int groups, ur_stream_t s) {
     UR_REQUIRE(x && y && rows > 0 && c > 0 && groups > 0 && c % groups == 0, "channel_shuffle: bad arguments");
     const long long total = rows * c;
+    UR_REQUIRE_32BIT(total, "channel_shuffle");
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_shuffle_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0,
                                                 (hipStream_t)s, (const T*)x, (T*)y, rows, c, groups));
     return ur_check_launch("channel_shuffle");
@@ -408,6 +418,7 @@ int ur_channel_shuffle(const void* x, void* y, int dtype, long long rows, int c,
 int ur_add_inplace(void* a, const void* b, int dtype, long long count, ur_stream_t s) {
     UR_REQUIRE(a && b && count > 0, "add_inplace: bad arguments");
     UR_REQUIRE(al(a, 4 * esize(dtype)) && al(b, 4 * esize(dtype)), "add_inplace: buffers must be 4-element aligned");
+    UR_REQUIRE_32BIT(count, "add_inplace");
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((add_inplace_kernel<T>), dim3(ur_grid_1d(count / 4 + 1, NT)), dim3(NT), 0,
                                                 (hipStream_t)s, (T*)a, (const T*)b, count));
     return ur_check_launch("add_inplace");
@@ -415,6 +426,7 @@ int ur_add_inplace(void* a, const void* b, int dtype, long long count, ur_stream
 
 int ur_act_fwd(const void* x, void* y, int dtype, long long count, int act, float slope, ur_stream_t s) {
     UR_REQUIRE(x && y && count > 0 && act >= UR_ACT_NONE && act <= UR_ACT_HSWISH, "act_fwd: bad arguments");
+    UR_REQUIRE_32BIT(count, "act_fwd");
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((act_fwd_kernel<T>), dim3(ur_grid_1d(count, NT)), dim3(NT), 0,
                                                 (hipStream_t)s, (const T*)x, (T*)y, count, act, slope));
     return ur_check_launch("act_fwd");
@@ -422,6 +434,7 @@ int ur_act_fwd(const void* x, void* y, int dtype, long long count, int act, floa
 
 int ur_act_bwd(const void* dy, const void* x, void* dx, int dtype, long long count, int act, float slope, ur_stream_t s) {
     UR_REQUIRE(dy && x && dx && count > 0 && act >= UR_ACT_NONE && act <= UR_ACT_HSWISH, "act_bwd: bad arguments");
+    UR_REQUIRE_32BIT(count, "act_bwd");
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(ur_grid_1d(count, NT)), dim3(NT), 0,
                                                 (hipStream_t)s, (const T*)dy, (const T*)x, (T*)dx, count, act, slope));
     return ur_check_launch("act_bwd");
