@@ -1,0 +1,152 @@
+"""GPU parity at the sizes BASELINE.json names: one Cityscapes-shaped 512x1024 image through
+UResNetNewEUCB(19,3,64) (config 3), one 224x224 MiniImageNet batch through U_ResNet(100,3) (config 2)
+and the Ice-Seg inference path (config 5), each against the CPU oracle run on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import uresnet_amd
+    uresnet_amd._lib.load()
+    return uresnet_amd
+
+
+def host(pkg, t):
+    t = t.detach()
+    if t.dim() == 4:
+        return pkg.ops.to_nchw_raw(pkg.ops._g(t), torch.float32).cpu()
+    return t.float().cpu()
+
+
+def _seg_inputs(h, w, classes=19, b=1):
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(b, 3, h, w, generator=g)
+    y = torch.randint(0, classes, (b, h, w), generator=g)
+    y[torch.rand(y.shape, generator=g) < 0.1] = 255
+    return x, y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_config3_full_resolution_step_matches_oracle(pkg, oracle, dtype):
+    """fp32 storage is checked against the plain oracle; bf16 storage against the oracle with bf16 storage
+    emulation (same tensors rounded, fp32 arithmetic inside), which keeps ReLU masks comparable."""
+    torch.manual_seed(0)
+    ref = oracle.UResNetNewEUCB(19, 3, 64).train()
+    bf16 = dtype == torch.bfloat16
+    if bf16:
+        oracle.emulate_bf16_storage(ref)
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    x, y = _seg_inputs(512, 1024)
+    ro = ref(x)
+    rl = oracle.compute_loss(ro, y)
+    rl.backward()
+    m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 64).set_compute_dtype(dtype)
+    m.load_state_dict(state0)
+    m.to(DEV).train()
+    out = m(x.to(DEV))
+    loss = pkg.train.compute_loss(out, y.to(DEV))
+    loss.backward()
+    assert out.shape == (1, 19, 512, 1024)
+    assert rel_l2(host(pkg, out), ro.detach()) < (2e-4 if not bf16 else 4e-2)
+    assert abs(loss.item() - rl.item()) < (1e-5 if not bf16 else 2e-3) * abs(rl.item())
+    # Gradients: with 5e5 pixels x 41 ReLU layers a handful of pre-activations sit within round-off of zero and
+    # flip their mask (each flip shifts every upstream gradient, see tests/test_hip_parity.py); the reference's
+    # own fp32-vs-fp64 gradients differ by 1e-3 median at 64x128.
+    gref = dict((k, p.grad) for k, p in ref.named_parameters())
+    gmax = max(g.norm() for g in gref.values())
+    errs = []
+    for k, p in m.named_parameters():
+        if p.grad is None or gref[k].norm() < 1e-6 * gmax:
+            continue
+        errs.append(rel_l2(p.grad.cpu(), gref[k]))
+    # bf16: the randomly initialised 41-BN-layer network amplifies a 1-ulp bf16 difference in one activation by
+    # ~1e4 on the way back (measured: two bf16 runs that differ only in fp32 summation order -- tiled vs generic
+    # kernels -- disagree by 3e-2 at the first layer reached in backward and 2.5e-1 at the deepest); the reference's
+    # own bf16-autocast gradients sit 0.3-0.46 from its fp32 ones.  Per-operator tests pin the kernels at 1e-2.
+    assert np.median(errs) < (2e-2 if not bf16 else 0.6), np.median(errs)
+    # running statistics updated like PyTorch (momentum 0.1, unbiased variance)
+    sd_r, sd_m = ref.state_dict(), m.state_dict()
+    for k in ("conv1.1.running_mean", "up4.conv.4.running_var", "out_conv.0.running_var", "Upsample.up_dwc2.1.running_mean"):
+        assert rel_l2(sd_m[k].cpu(), sd_r[k]) < (1e-4 if not bf16 else 1e-2), k
+    assert int(sd_m["conv1.1.num_batches_tracked"]) == 1
+
+
+def test_config3_tiled_and_generic_kernels_agree_at_full_size(pkg):
+    """Two independent HIP implementations of the 3x3 layers (LDS-tiled vs gather implicit GEMM) must produce the
+    same bf16 training step on a full-resolution image."""
+    torch.manual_seed(0)
+    x, y = _seg_inputs(512, 1024)
+    res = {}
+    for tile in (True, False):
+        pkg.ops.use_tile_kernel = tile
+        try:
+            torch.manual_seed(0)
+            m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 64).set_compute_dtype(torch.bfloat16).to(DEV).train()
+            out = m(x.to(DEV))
+            loss = pkg.train.compute_loss(out, y.to(DEV))
+            loss.backward()
+            res[tile] = (host(pkg, out), loss.item(), m.in_conv[3].weight.grad.cpu(), m.down4[1][3].weight.grad.cpu())
+        finally:
+            pkg.ops.use_tile_kernel = True
+    assert rel_l2(res[True][0], res[False][0]) < 2e-2
+    assert abs(res[True][1] - res[False][1]) < 2e-3
+    # gradients: the two kernels round y differently in the last bf16 bit now and then, which flips ReLU masks
+    assert rel_l2(res[True][2], res[False][2]) < 0.3
+    assert rel_l2(res[True][3], res[False][3]) < 0.3
+
+
+def test_config2_mini_imagenet_step_matches_oracle(pkg, oracle):
+    torch.manual_seed(0)
+    ref = oracle.MiniU_ResNet(100, 3).train()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 3, 224, 224, generator=g)
+    y = torch.randint(0, 100, (2,), generator=g)
+    ro = ref(x)
+    rl = oracle.cls_loss(ro, y)
+    rl.backward()
+    m = pkg.modules.U_ResNet_MiniImageNet.U_ResNet(100, 3).set_compute_dtype(torch.float32)
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).train()
+    out = m(x.to(DEV))
+    loss = pkg.train.cross_entropy_loss(out, y.to(DEV))
+    loss.backward()
+    assert rel_l2(out.float().cpu(), ro.detach()) < 5e-4
+    assert abs(loss.item() - rl.item()) < 1e-4
+    unused_ref = sorted(k for k, p in ref.named_parameters() if p.grad is None)
+    unused = sorted(k for k, p in m.named_parameters() if p.grad is None)
+    assert unused == unused_ref and len(unused) > 0         # up2..up4 and CBPooling never receive gradients
+    assert rel_l2(m.fc.weight.grad.cpu(), ref.fc.weight.grad) < 2e-3
+
+
+def test_config5_ice_seg_inference_mask(pkg, oracle):
+    """eval(): running-statistics BN, sigmoid(logits) > 0.5 mask; batch of 4 512x512 images."""
+    torch.manual_seed(0)
+    ref = oracle.UResNet(1, 3, 64)
+    # a few training steps on small crops so the running statistics are not the initial (0, 1)
+    g = torch.Generator().manual_seed(3)
+    ref.train()
+    with torch.no_grad():
+        for _ in range(2):
+            ref(torch.randn(2, 3, 64, 64, generator=g))
+    ref.eval()
+    x = torch.randn(4, 3, 512, 512, generator=g)
+    with torch.no_grad():
+        ro = ref(x)
+    want = oracle.sigmoid_mask(ro)
+    for dtype, tol, flips in ((torch.float32, 2e-4, 1e-4), (torch.bfloat16, 6e-2, 3e-2)):
+        m = pkg.modules.U_ResNet.UResNet(1, 3, 64).set_compute_dtype(dtype)
+        m.load_state_dict(ref.state_dict())
+        m.to(DEV).eval()
+        with torch.no_grad():
+            out = m(x.to(DEV))
+            mask = pkg.train.sigmoid_mask(out)
+        assert rel_l2(host(pkg, out), ro) < tol
+        got = host(pkg, mask.float()).bool()
+        assert (got != want).float().mean().item() < flips       # only logits within round-off of 0 may flip
