@@ -9,6 +9,22 @@ namespace {
 
 constexpr int NT = 256;
 
+// 4 consecutive channels as loaded (8 bytes of bf16 / 16 bytes of fp32); converted to fp32 only when consumed,
+// so a software-prefetched pixel costs 2 (bf16) or 4 (fp32) registers per tap
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> {
+    bf16x4_t v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x4_t*>(p); }
+    __device__ __forceinline__ void zero() { v = bf16x4_t{0, 0, 0, 0}; }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+};
+template <> struct Raw4<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+
 // out[a] = sum_{tap,b} in[p + off(tap)][b] * Wt(a, b, tap)
 //   forward       : off = (ky-1, kx-1), Wt = w[q*4+a][b][tap]
 //   backward-data : off = (1-ky, 1-kx), Wt = w[q*4+b][a][tap]
@@ -76,12 +92,13 @@ __global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__
         }
     }
     const int P = N * H * W;                     // < 2^31 (checked on the host): 32-bit index arithmetic
-    for (int pix = blockIdx.x * PS + pslot; pix < P; pix += gridDim.x * PS) {
+    const int pstep = gridDim.x * PS;
+    // the 9 taps of the NEXT pixel are in flight while the current pixel is multiplied
+    auto load_taps = [&](int pix, Raw4<T>* taps) {
         const int t = pix / W;
         const int x = pix - t * W;
         const int n = t / H;
         const int y = t - n * H;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = DGRAD ? y + 1 - ky : y + ky - 1;
@@ -89,22 +106,36 @@ __global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int xx = DGRAD ? x + 1 - kx : x + kx - 1;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (yok && (unsigned)xx < (unsigned)W) v = ur_load4(in + ((size_t)((n * H + yy) * W + xx)) * C + q * 4);
-                const float vi[4] = {v.x, v.y, v.z, v.w};
-                const int tap = ky * 3 + kx;
-                if constexpr (CPG == 1) {
+                if (yok && (unsigned)xx < (unsigned)W) taps[ky * 3 + kx].load(in + ((size_t)((n * H + yy) * W + xx)) * C + q * 4);
+                else taps[ky * 3 + kx].zero();
+            }
+        }
+    };
+    Raw4<T> cur[9], nxt[9];
+    int pix = blockIdx.x * PS + pslot;
+    if (pix < P) load_taps(pix, cur);
+    for (; pix < P; pix += pstep) {
+        const bool more = pix + pstep < P;
+        if (more) load_taps(pix + pstep, nxt);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) acc[a] += vi[a] * wr[tap][a];
-                } else {
+        for (int tap = 0; tap < 9; ++tap) {
+            const float vi[4] = {cur[tap].get(0), cur[tap].get(1), cur[tap].get(2), cur[tap].get(3)};
+            if constexpr (CPG == 1) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a) acc[a] += vi[a] * wr[tap][a];
+            } else {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) acc[a] += vi[b] * wr[tap][a * 4 + b];
-                }
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a] += vi[b] * wr[tap][a * 4 + b];
             }
         }
         ur_store4(out + (size_t)pix * C + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        if (more) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) cur[tap] = nxt[tap];
+        }
     }
 }
 
@@ -147,33 +178,49 @@ __global__ __launch_bounds__(NT) void gconv3x3_wgrad_kernel(const T* __restrict_
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[t][v] = 0.f;
         if (slot < slots && q < Q) {
-            for (int pix = blockIdx.x * slots + slot; pix < (int)P; pix += gridDim.x * slots) {
+            const int pstep = gridDim.x * slots;
+            auto load_pix = [&](int pix, Raw4<T>& g, Raw4<T>* taps) {
                 const int t = pix / W;
                 const int xx0 = pix - t * W;
                 const int n = t / H;
                 const int yy0 = t - n * H;
-                const float4 g4 = ur_load4(dy + (size_t)pix * C + q * 4);
-                const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+                g.load(dy + (size_t)pix * C + q * 4);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int yy = yy0 + ky - 1;
-                    if ((unsigned)yy >= (unsigned)H) continue;
+                    const bool yok = (unsigned)yy < (unsigned)H;
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = xx0 + kx - 1;
-                        if ((unsigned)xx >= (unsigned)W) continue;
-                        const float4 v4 = ur_load4(x + ((size_t)((n * H + yy) * W + xx)) * C + q * 4);
-                        const float vi[4] = {v4.x, v4.y, v4.z, v4.w};
-                        if constexpr (CPG == 1) {
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) acc[ky * 3 + kx][a] += g[a] * vi[a];
-                        } else {
-#pragma unroll
-                            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                                for (int b = 0; b < 4; ++b) acc[ky * 3 + kx][a * 4 + b] += g[a] * vi[b];
-                        }
+                        if (yok && (unsigned)xx < (unsigned)W) taps[ky * 3 + kx].load(x + ((size_t)((n * H + yy) * W + xx)) * C + q * 4);
+                        else taps[ky * 3 + kx].zero();
                     }
+                }
+            };
+            Raw4<T> gc, gn, cur[9], nxt[9];
+            int pix = blockIdx.x * slots + slot;
+            if (pix < (int)P) load_pix(pix, gc, cur);
+            for (; pix < (int)P; pix += pstep) {
+                const bool more = pix + pstep < (int)P;
+                if (more) load_pix(pix + pstep, gn, nxt);
+                const float g[4] = {gc.get(0), gc.get(1), gc.get(2), gc.get(3)};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float vi[4] = {cur[tap].get(0), cur[tap].get(1), cur[tap].get(2), cur[tap].get(3)};
+                    if constexpr (CPG == 1) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) acc[tap][a] += g[a] * vi[a];
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) acc[tap][a * 4 + b] += g[a] * vi[b];
+                    }
+                }
+                if (more) {
+                    gc = gn;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) cur[tap] = nxt[tap];
                 }
             }
         }
