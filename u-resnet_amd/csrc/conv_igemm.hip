@@ -40,6 +40,7 @@ struct IgemmParams {
     int scatter;         // 1: ConvTranspose 2x2 s2 scatter epilogue (n = (dy,dx,co))
     int cout_t;          // scatter: channels of the transposed conv's output
     int mtiles, ntiles;
+    int vec_store;       // 1: 16-byte stores are legal (pitch, column count, base address and scatter width all aligned)
 };
 
 template <typename T> struct LdsPitch;
@@ -243,6 +244,66 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmParams p) {
     float s1[NT], s2[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b) { s1[b] = 0.f; s2[b] = 0.f; }
+    if (p.vec_store) {
+        // The accumulator layout gives a lane one column and 32 rows; stores of one element per lane would be
+        // 2-4 bytes each.  Stage each 64 x 32 sub-tile in the wave's own rows of As (no other wave reads them)
+        // and write it back out as 16-byte row pieces.
+        constexpr int VE = 16 / (int)sizeof(T);      // elements per 16-byte piece
+        constexpr int CPR = 32 / VE;                 // pieces per 32-column row
+        T* stage = As + wave * 64 * PITCH;
+        size_t rowoff[CPR];
+        bool rowok[CPR];
+#pragma unroll
+        for (int i = 0; i < CPR; ++i) {
+            const int row = (lane + 64 * i) / CPR;
+            const int m = m0 + wave * 64 + row;
+            rowok[i] = m < p.M;
+            if (!p.scatter) {
+                rowoff[i] = (size_t)m * p.dst_ld;
+            } else {
+                const int img = m / (p.OH * p.OW);
+                const int rem = m - img * (p.OH * p.OW);
+                const int y = rem / p.OW, x = rem - y * p.OW;
+                rowoff[i] = ((size_t)(img * 2 * p.OH + 2 * y) * (2 * p.OW) + 2 * x) * p.dst_ld;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = n0 + b * 32 + lrow;
+            const bool nok = n < p.Ncols;
+            const float bv = (p.bias && nok) ? p.bias[p.scatter ? n % p.cout_t : n] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    const float v = acc[a][b][r] + bv;
+                    stage[row * PITCH + lrow] = ur_from_float<T>(v);
+                    if (m0 + wave * 64 + row < p.M && nok) { s1[b] += v; s2[b] += v * v; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < CPR; ++i) {
+                const int idx = lane + 64 * i;
+                const int row = idx / CPR, piece = idx % CPR;
+                const int nn = n0 + b * 32 + piece * VE;
+                if (rowok[i] && nn < p.Ncols) {
+                    size_t off;
+                    if (!p.scatter) {
+                        off = rowoff[i] + nn;
+                    } else {
+                        const int tap = nn / p.cout_t, co = nn - tap * p.cout_t;
+                        off = rowoff[i] + ((size_t)(tap >> 1) * (2 * p.OW) + (tap & 1)) * p.dst_ld + co;
+                    }
+                    *reinterpret_cast<float4*>(dst + off) = *reinterpret_cast<const float4*>(stage + row * PITCH + piece * VE);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int n = n0 + b * 32 + lrow;
@@ -273,6 +334,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmParams p) {
                 }
             }
         }
+    }
     }
     if (p.stats) {
 #pragma unroll
@@ -340,6 +402,9 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
     const int grid = round_up(p.mtiles, 8) * p.ntiles;
     const uintptr_t sa = (uintptr_t)p.src;
     const bool vec = (p.C % 8 == 0) && (p.src_ld % 8 == 0) && (sa % 16 == 0);
+    constexpr int VE = 16 / (int)sizeof(T);
+    p.vec_store = (p.dst_ld % VE == 0) && (p.Ncols % VE == 0) && ((uintptr_t)p.dst % 16 == 0) &&
+                  (!p.scatter || p.cout_t % VE == 0);
     if (vec) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, true>), dim3(grid), dim3(NTHREADS), 0, st, p);
     else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, false>), dim3(grid), dim3(NTHREADS), 0, st, p);
     return ur_check_launch("conv_igemm");
