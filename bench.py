@@ -21,6 +21,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (no sparsity)
+HBM_PEAK_GBS = 8000.0                # MI355X HBM3E peak (about 6300 GB/s is achievable by a streaming kernel)
 FP32_MATRIX_PEAK_TFLOPS = 157.3
 
 
@@ -159,13 +160,21 @@ def main():
                     "frac": dom["frac"], "traffic": None, "launches": dom["launches"],
                     "avg_launch_ms": dom["avg_launch_ms"], "flops_per_launch": dom["flops_per_launch"],
                     "time_share_of_step": dom["time_share_of_step"], "other_kernels": summary}
-            conv_flops = sum(k[1] for k in kernels.values())
-            conv_secs = sum(k[2] for k in kernels.values())
+            for tag, (n, by, sec) in kernels.items():
+                if tag.startswith("hbm:") and n:
+                    summary[tag[4:] + " (HBM-bound, algorithmic bytes)"] = {
+                        "bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4), "launches": n,
+                        "avg_launch_ms": round(sec / n * 1e3, 4), "bytes_per_launch": by / n,
+                        "time_share_of_step": round(sec / elapsed, 3)}
+            conv_flops = sum(k[1] for t, k in kernels.items() if not t.startswith("hbm:"))
+            conv_secs = sum(k[2] for t, k in kernels.items() if not t.startswith("hbm:"))
             roof["all_conv_mfma_util"] = round(conv_flops / conv_secs / 1e12 / peak, 4)
             roof["all_conv_time_share_of_step"] = round(conv_secs / elapsed, 3)
         if args.per_shape:
             for (tag, shape), (n, fl, sec) in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:40]:
-                print("%-12s %-34s calls %4d  %8.3f ms/step  %7.1f TF" % (tag, shape, n, sec / args.steps * 1e3, fl / sec / 1e12), file=sys.stderr)
+                print("%-12s %-34s calls %4d  %8.3f ms/step  %7.1f %s" % (tag, shape, n, sec / args.steps * 1e3, fl / sec / 1e12,
+                                                                          "TB/s" if tag.startswith("hbm:") else "TF"), file=sys.stderr)
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(H, W)

@@ -5,6 +5,13 @@
 // one partial row per workgroup (summed later in a fixed order: reproducible, no atomics).
 #include "ur_common.h"
 
+#ifndef UR_BN_RED_UNROLL
+#define UR_BN_RED_UNROLL 1
+#endif
+#ifndef UR_BN_RED_VEC8
+#define UR_BN_RED_VEC8 0
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -26,6 +33,8 @@ __device__ __forceinline__ void colreduce_body(const Op& op, long long rows, int
 #pragma unroll
         for (int i = 0; i < VEC * NV; ++i) acc[i] = 0.f;
         if (slot < slots && col < C) {
+            // independent rows: unrolled so that the loads of several rows are in flight together
+#pragma unroll UR_BN_RED_UNROLL
             for (long long r = (long long)blockIdx.x * slots + slot; r < rows; r += (long long)gridDim.x * slots)
                 op(r, col, acc);
         }
@@ -52,8 +61,20 @@ __device__ __forceinline__ void colreduce_body(const Op& op, long long rows, int
 template <typename T, int VEC> struct RowVec {
     float v[VEC];
     __device__ __forceinline__ void load(const T* p) {
-        if constexpr (VEC == 4) { float4 f = ur_load4(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+        if constexpr (VEC == 8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { float4 f = ur_load4(p + 4 * h); v[4 * h] = f.x; v[4 * h + 1] = f.y; v[4 * h + 2] = f.z; v[4 * h + 3] = f.w; }
+        } else if constexpr (VEC == 4) { float4 f = ur_load4(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
         else v[0] = ur_to_float(*p);
+    }
+};
+
+template <> struct RowVec<bf16_t, 8> {
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
     }
 };
 
@@ -228,21 +249,10 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ y,
     }
 }
 
-// bf16, 8 channels per thread (16-byte accesses); scale/shift folded per channel: z = act(y*a + b (+res))
-__global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __restrict__ y, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, const bf16_t* __restrict__ res,
-                                                               int act, bf16_t* __restrict__ z, long long total, int C) {
-    const long long stride = (long long)gridDim.x * NT * 8;
-    const int cstep = (int)(stride % C);
-    int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 8) % C);
-    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8; i < total; i += stride) {
-        const int c = cnext;
-        cnext += cstep; if (cnext >= C) cnext -= C;
-        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
-        bf16x8_t r8 = y8;
-        if (res) r8 = *reinterpret_cast<const bf16x8_t*>(res + i);
-        float m[8], is[8], ga[8], be[8];
+// Per-channel constants of 8 consecutive channels, kept in registers.
+struct Chan8 {
+    float m[8], is[8], ga[8], be[8];
+    __device__ __forceinline__ void load(const float* mean, const float* invstd, const float* gamma, const float* beta, int c) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float4 a = *reinterpret_cast<const float4*>(mean + c + 4 * h), b = *reinterpret_cast<const float4*>(invstd + c + 4 * h);
@@ -252,15 +262,57 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __r
             ga[4 * h] = d.x; ga[4 * h + 1] = d.y; ga[4 * h + 2] = d.z; ga[4 * h + 3] = d.w;
             be[4 * h] = e.x; be[4 * h + 1] = e.y; be[4 * h + 2] = e.z; be[4 * h + 3] = e.w;
         }
+    }
+};
+
+// bf16, 8 channels per thread (16-byte accesses).  The grid stride is a multiple of C for the power-of-two
+// channel counts of the network, so a thread keeps its 8 channels for the whole walk (FIXED): constants are
+// loaded once and UNROLL independent 16-byte loads are in flight per tensor before the first use.
+constexpr int EW_UNROLL = 4;
+
+template <bool FIXED, bool RES>
+__global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const bf16_t* __restrict__ res,
+                                                               int act, bf16_t* __restrict__ z, long long total, int C) {
+    const long long stride = (long long)gridDim.x * NT * 8;
+    const int cstep = (int)(stride % C);
+    int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 8) % C);
+    Chan8 k;
+    if (FIXED) k.load(mean, invstd, gamma, beta, cnext);
+    auto one = [&](const bf16x8_t& y8, const bf16x8_t& r8, long long i) {
         bf16x8_t o8;
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
-            float o = ((float)y8[v] - m[v]) * is[v] * ga[v] + be[v];      // same operation order as the 4-wide kernel
-            if (res) o += (float)r8[v];
+            float o = ((float)y8[v] - k.m[v]) * k.is[v] * k.ga[v] + k.be[v];      // same operation order as the 4-wide kernel
+            if (RES) o += (float)r8[v];
             if (act) o = fmaxf(o, 0.f);
             o8[v] = (bf16_t)o;
         }
         *reinterpret_cast<bf16x8_t*>(z + i) = o8;
+    };
+    long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8;
+    if (FIXED) {
+        for (; i + (EW_UNROLL - 1) * stride < total; i += EW_UNROLL * stride) {
+            bf16x8_t y8[EW_UNROLL], r8[EW_UNROLL];
+#pragma unroll
+            for (int u = 0; u < EW_UNROLL; ++u) {
+                y8[u] = *reinterpret_cast<const bf16x8_t*>(y + i + u * stride);
+                if (RES) r8[u] = *reinterpret_cast<const bf16x8_t*>(res + i + u * stride); else r8[u] = y8[u];
+            }
+#pragma unroll
+            for (int u = 0; u < EW_UNROLL; ++u) one(y8[u], r8[u], i + u * stride);
+        }
+    }
+    for (; i < total; i += stride) {
+        if (!FIXED) {
+            k.load(mean, invstd, gamma, beta, cnext);
+            cnext += cstep; if (cnext >= C) cnext -= C;
+        }
+        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
+        bf16x8_t r8 = y8;
+        if (RES) r8 = *reinterpret_cast<const bf16x8_t*>(res + i);
+        one(y8, r8, i);
     }
 }
 
@@ -320,7 +372,8 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
     }
 }
 
-// bf16, 8 channels per thread: 16-byte tensor accesses and float4 parameter loads
+// bf16, 8 channels per thread: 16-byte tensor accesses, constants in registers, EW_UNROLL loads per tensor in flight
+template <bool FIXED, bool HAVE_Z, bool DRES>
 __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
     const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y, const bf16_t* __restrict__ z, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -329,43 +382,72 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
     const long long stride = (long long)gridDim.x * NT * 8;
     const int cstep = (int)(stride % C);          // channel offset advances mod C: no 64-bit division in the loop
     int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 8) % C);
-    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8; i < total; i += stride) {
-        const int c = cnext;
-        cnext += cstep; if (cnext >= C) cnext -= C;
-        const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(dz + i);
-        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
-        bf16x8_t z8 = g8;
-        if (act && z) z8 = *reinterpret_cast<const bf16x8_t*>(z + i);
-        float m[8], is[8], ga[8], be[8], s0[8], s1[8];
+    Chan8 k;
+    float s0[8], s1[8];
+    auto load_consts = [&](int c) {
+        k.load(mean, invstd, gamma, beta, c);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 a = *reinterpret_cast<const float4*>(mean + c + 4 * h), b = *reinterpret_cast<const float4*>(invstd + c + 4 * h);
-            const float4 d = *reinterpret_cast<const float4*>(gamma + c + 4 * h), e = *reinterpret_cast<const float4*>(beta + c + 4 * h);
-            m[4 * h] = a.x; m[4 * h + 1] = a.y; m[4 * h + 2] = a.z; m[4 * h + 3] = a.w;
-            is[4 * h] = b.x; is[4 * h + 1] = b.y; is[4 * h + 2] = b.z; is[4 * h + 3] = b.w;
-            ga[4 * h] = d.x; ga[4 * h + 1] = d.y; ga[4 * h + 2] = d.z; ga[4 * h + 3] = d.w;
-            be[4 * h] = e.x; be[4 * h + 1] = e.y; be[4 * h + 2] = e.z; be[4 * h + 3] = e.w;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
             if (!eval) {
-                const float4 p = *reinterpret_cast<const float4*>(sums + (c + 4 * h) * 2), q = *reinterpret_cast<const float4*>(sums + (c + 4 * h) * 2 + 4);
-                s0[4 * h] = p.x; s1[4 * h] = p.y; s0[4 * h + 1] = p.z; s1[4 * h + 1] = p.w;
-                s0[4 * h + 2] = q.x; s1[4 * h + 2] = q.y; s0[4 * h + 3] = q.z; s1[4 * h + 3] = q.w;
+                p = *reinterpret_cast<const float4*>(sums + (c + 4 * h) * 2);
+                q = *reinterpret_cast<const float4*>(sums + (c + 4 * h) * 2 + 4);
             }
+            s0[4 * h] = p.x * inv_count; s1[4 * h] = p.y * inv_count; s0[4 * h + 1] = p.z * inv_count; s1[4 * h + 1] = p.w * inv_count;
+            s0[4 * h + 2] = q.x * inv_count; s1[4 * h + 2] = q.y * inv_count; s0[4 * h + 3] = q.z * inv_count; s1[4 * h + 3] = q.w * inv_count;
         }
+    };
+    if (FIXED) load_consts(cnext);
+    auto one = [&](const bf16x8_t& g8, const bf16x8_t& y8, const bf16x8_t& z8, long long i) {
         bf16x8_t o8, r8;
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
-            const float xh = ((float)y8[v] - m[v]) * is[v];
+            const float xh = ((float)y8[v] - k.m[v]) * k.is[v];
             float pre = 1.f;
-            if (act && z) pre = (float)z8[v];
-            else if (act) pre = xh * ga[v] + be[v];
+            if (HAVE_Z) pre = (float)z8[v];
+            else if (act) pre = xh * k.ga[v] + k.be[v];
             const float gv = pre > 0.f ? (float)g8[v] : 0.f;
-            const float k = ga[v] * is[v];
-            const float o = eval ? k * gv : k * (gv - s0[v] * inv_count - xh * s1[v] * inv_count);
+            const float kk = k.ga[v] * k.is[v];
+            const float o = eval ? kk * gv : kk * (gv - s0[v] - xh * s1[v]);
             o8[v] = (bf16_t)o; r8[v] = (bf16_t)gv;
         }
         *reinterpret_cast<bf16x8_t*>(dy + i) = o8;
-        if (dres) *reinterpret_cast<bf16x8_t*>(dres + i) = r8;
+        if (DRES) *reinterpret_cast<bf16x8_t*>(dres + i) = r8;
+    };
+    long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8;
+    if (FIXED) {
+        constexpr int U = HAVE_Z ? 2 : EW_UNROLL;
+        for (; i + (U - 1) * stride < total; i += U * stride) {
+            bf16x8_t g8[U], y8[U], z8[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                g8[u] = *reinterpret_cast<const bf16x8_t*>(dz + i + u * stride);
+                y8[u] = *reinterpret_cast<const bf16x8_t*>(y + i + u * stride);
+                if (HAVE_Z) z8[u] = *reinterpret_cast<const bf16x8_t*>(z + i + u * stride); else z8[u] = g8[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(g8[u], y8[u], z8[u], i + u * stride);
+        }
     }
+    for (; i < total; i += stride) {
+        if (!FIXED) {
+            load_consts(cnext);
+            cnext += cstep; if (cnext >= C) cnext -= C;
+        }
+        const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(dz + i);
+        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
+        bf16x8_t z8 = g8;
+        if (HAVE_Z) z8 = *reinterpret_cast<const bf16x8_t*>(z + i);
+        one(g8, y8, z8, i);
+    }
+}
+
+// Elementwise grid: enough workgroups to fill the chip several times over, each thread walking EW_UNROLL+ pieces.
+int ew_grid(long long pieces) {
+    long long g = (pieces + (long long)NT * EW_UNROLL - 1) / ((long long)NT * EW_UNROLL);
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
 }
 
 int reduce_grid(long long rows, int C, int vec) {
@@ -374,7 +456,7 @@ int reduce_grid(long long rows, int C, int vec) {
     int slots = NT / cqb;
     long long g = (rows + (long long)slots * 8 - 1) / ((long long)slots * 8);     // >= 8 rows per thread
     if (g < 1) g = 1;
-    if (g > 1024) g = 1024;
+    if (g > 2048) g = 2048;
     return (int)g;
 }
 
@@ -390,6 +472,10 @@ int ur_bn_stats(const void* y, int dtype, long long rows, int c, float* partial,
     UR_REQUIRE(y && partial && rows > 0 && c > 0, "bn_stats: bad arguments");
     const bool vec = (c % 4 == 0) && aligned16(y);
     const int grid = reduce_grid(rows, c, c % 4 == 0 ? 4 : 1);
+    if (UR_BN_RED_VEC8 && dtype == UR_BF16 && vec && c % 8 == 0) {
+        hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 8>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)y, rows, c, partial);
+        return ur_check_launch("bn_stats");
+    }
     UR_DISPATCH_DTYPE(dtype, {
         if (vec) hipLaunchKernelGGL((bn_stats_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)y, rows, c, partial);
         else hipLaunchKernelGGL((bn_stats_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)y, rows, c, partial);
@@ -447,8 +533,14 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(z) && aligned16(residual) && aligned16(mean) &&
                      aligned16(invstd) && aligned16(gamma) && aligned16(beta);
     if (dtype == UR_BF16 && vec && c % 8 == 0) {
-        hipLaunchKernelGGL(bn_act_fwd_bf16x8_kernel, dim3(ur_grid_1d(total / 8, NT)), dim3(NT), 0, (hipStream_t)s,
-                           (const bf16_t*)y, mean, invstd, gamma, beta, (const bf16_t*)residual, act, (bf16_t*)z, total, c);
+        const int grid = ew_grid(total / 8);
+        const bool fixed = ((long long)grid * NT * 8) % c == 0;
+#define UR_BN_FWD(FIXED, RES)                                                                                             \
+    hipLaunchKernelGGL((bn_act_fwd_bf16x8_kernel<FIXED, RES>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)y,  \
+                       mean, invstd, gamma, beta, (const bf16_t*)residual, act, (bf16_t*)z, total, c)
+        if (fixed) { if (residual) UR_BN_FWD(true, true); else UR_BN_FWD(true, false); }
+        else { if (residual) UR_BN_FWD(false, true); else UR_BN_FWD(false, false); }
+#undef UR_BN_FWD
         return ur_check_launch("bn_act_fwd");
     }
     UR_DISPATCH_DTYPE(dtype, {
@@ -467,6 +559,11 @@ int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const flo
     UR_REQUIRE(!act || z || (gamma && beta), "bn_act_bwd_reduce: the activation mask needs z or (gamma, beta)");
     const bool vec = (c % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(z);
     const int grid = reduce_grid(rows, c, c % 4 == 0 ? 4 : 1);
+    if (UR_BN_RED_VEC8 && dtype == UR_BF16 && vec && c % 8 == 0) {
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 8>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)dz,
+                           (const bf16_t*)y, (const bf16_t*)z, mean, invstd, gamma, beta, act, rows, c, partial);
+        return ur_check_launch("bn_act_bwd_reduce");
+    }
     UR_DISPATCH_DTYPE(dtype, {
         if (vec) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
                                     (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, partial);
@@ -497,9 +594,21 @@ int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const floa
     const bool al = aligned16(dz) && aligned16(y) && aligned16(z) && aligned16(dy) && aligned16(dres);
     if (dtype == UR_BF16 && c % 8 == 0 && al && beta && aligned16(mean) && aligned16(invstd) && aligned16(gamma) &&
         aligned16(beta) && aligned16(sums)) {
-        hipLaunchKernelGGL(bn_act_bwd_apply_bf16x8_kernel, dim3(ur_grid_1d(total / 8, NT)), dim3(NT), 0, (hipStream_t)s,
-                           (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, mean, invstd, gamma, beta, sums, act, eval,
-                           inv_count, (bf16_t*)dy, (bf16_t*)dres, total, c);
+        const int grid = ew_grid(total / 8);
+        const bool fixed = ((long long)grid * NT * 8) % c == 0;
+        const bool have_z = act && z;
+#define UR_BN_BWD(FIXED, HZ, DR)                                                                                          \
+    hipLaunchKernelGGL((bn_act_bwd_apply_bf16x8_kernel<FIXED, HZ, DR>), dim3(grid), dim3(NT), 0, (hipStream_t)s,           \
+                       (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, mean, invstd, gamma, beta, sums, act, eval,  \
+                       inv_count, (bf16_t*)dy, (bf16_t*)dres, total, c)
+        if (fixed) {
+            if (have_z) { if (dres) UR_BN_BWD(true, true, true); else UR_BN_BWD(true, true, false); }
+            else { if (dres) UR_BN_BWD(true, false, true); else UR_BN_BWD(true, false, false); }
+        } else {
+            if (have_z) { if (dres) UR_BN_BWD(false, true, true); else UR_BN_BWD(false, true, false); }
+            else { if (dres) UR_BN_BWD(false, false, true); else UR_BN_BWD(false, false, false); }
+        }
+#undef UR_BN_BWD
         return ur_check_launch("bn_act_bwd_apply");
     }
     const bool vec = (c % 4 == 0) && al;

@@ -32,7 +32,8 @@ constexpr int W_GROUPS = W_PIECES / 64;              // one group = one wave-wid
 constexpr int W_GROUP_ITERS = (W_GROUPS + 3) / 4;
 constexpr int W_BYTES = W_PIECES * 16;               // 18432
 constexpr int OUT_PITCH = 144;                       // bytes per staged output pixel (128 + 16: the two half-waves land on disjoint banks)
-constexpr int STEPS = 18;                            // (dx, dy, b) steps per slice
+constexpr int STEPS = 18;
+constexpr int COMMIT_STEP = 16;                      // step ahead of which the next slice's halo is written (loads had 16 steps to land)
 
 template <int R> struct Geo {
     static constexpr int TH = 4 * R;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // LDS operations a wave issues in step t of a slice, in issue order: halo writes, weight fragment t+2, row fragments
-constexpr int ops_write(int t, bool more, int nw) { return (more && t == 12) ? nw : 0; }
+constexpr int ops_write(int t, bool more, int nw) { return (more && t == COMMIT_STEP) ? nw : 0; }
 constexpr int ops_b(int t) { return t + 2 < STEPS ? 1 : 0; }
 constexpr int ops_a(int t, int na) { return (t % 6 == 1 && t / 6 < 2) ? na : 0; }
 constexpr int ops_all(int t, bool more, int nw, int na) { return ops_write(t, more, nw) + ops_b(t) + ops_a(t, na); }
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
         lds_read16<1024>(bq[1], bb);
         static_for<STEPS>([&](auto S) {
             constexpr int s = S, dx = s / 6, dy = (s % 6) / 2, b = s & 1;
-            if constexpr (MORE && s == 12) commit(oo);
+            if constexpr (MORE && s == COMMIT_STEP) commit(oo);
             if constexpr (s + 2 < STEPS) {
                 constexpr int s2 = s + 2, tap2 = ((s2 % 6) / 2) * 3 + s2 / 6;
                 lds_read16<(tap2 * 2 + (s2 & 1)) * 1024>(bq[s2 % 3], bb);

@@ -162,20 +162,27 @@ class PackedWeights:
         return packed
 
     def get(self, weight, d, mode):
+        """k-major matrix for the generic kernels.  `d` may describe the layer with its channel counts rounded
+        up to a multiple of 8 (see _pad8): the parameter is then zero-padded to that shape before packing."""
         key = (weight.data_ptr(), weight._version, _weights_epoch, d.dtype, d.cin, d.cout)
         hit = self._cache.get(mode)
         if hit is not None and hit[0] == key:
             return hit[1]
+        src = weight
+        if mode in (_lib.PACK_FWD, _lib.PACK_DGRAD) and tuple(weight.shape[:2]) != (d.cout, d.cin):
+            src = weight.new_zeros((d.cout, d.cin) + tuple(weight.shape[2:]))
+            src[:weight.shape[0], :weight.shape[1]].copy_(weight.detach())
         elems = query("ur_conv2d_packed_elems", C.byref(d), mode)
         packed = torch.empty(elems, dtype=torch.bfloat16 if d.dtype == _lib.UR_BF16 else torch.float32,
                              device=weight.device)
-        call("ur_conv2d_pack_weight", weight.data_ptr(), packed.data_ptr(), C.byref(d), mode, _stream())
+        call("ur_conv2d_pack_weight", src.data_ptr(), packed.data_ptr(), C.byref(d), mode, _stream())
         self._cache[mode] = (key, packed)
         return packed
 
 
-# Optional live kernel timing: when `kernel_timings` is a list, every dense-conv kernel launch is
-# bracketed by two events recorded on the stream it is launched on, together with its algorithmic FLOPs.
+# Optional live kernel timing: when `kernel_timings` is a list, every dense-conv and BatchNorm kernel launch is
+# bracketed by two events recorded on the stream it is launched on, together with its algorithmic FLOPs
+# (tags starting with "hbm:" carry algorithmic bytes instead).
 kernel_timings = None
 use_tile_kernel = True          # False forces the generic implicit-GEMM kernel (A/B comparisons, tests)
 
@@ -218,6 +225,28 @@ def _colsum(t2d_ptr, dtype_code, rows, c, ld, device):
     return out
 
 
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _pad_channels(x, cpad):
+    """(N, C, H, W) NHWC activation -> (N, cpad, H, W) with zero channels appended.  The generic kernels gather
+    8 channels per 16/32-byte load only when the channel count is a multiple of 8; a 3-channel image or a
+    19-class gradient would otherwise be gathered element by element."""
+    n, c, h, w = x.shape
+    xp = empty_nhwc(n, cpad, h, w, x.dtype, x.device).zero_()
+    call("ur_copy_channels", x.data_ptr(), c, 0, h, w, xp.data_ptr(), cpad, 0, h, w, 0, 0, n, c, _dt(x), _stream())
+    return xp
+
+
+def _crop_channels(x, c):
+    """Dense (N, c, H, W) NHWC copy of the first c channels."""
+    n, cx, h, w = x.shape
+    y = empty_nhwc(n, c, h, w, x.dtype, x.device)
+    call("ur_copy_channels", x.data_ptr(), cx, 0, h, w, y.data_ptr(), c, 0, h, w, 0, 0, n, c, _dt(x), _stream())
+    return y
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, packs, stride, pad, want_stats):
@@ -238,13 +267,16 @@ class _Conv2d(Function):
             with _Timed("tile_fwd", _conv_flops(d), d):
                 call("ur_conv3x3_tile_fwd", x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(stats), C.byref(d), _stream())
         else:
+            if cin % 8:
+                x = _pad_channels(x, _pad8(cin))
+                d = _desc(x.shape, cout, kh, kw, stride, pad, x.dtype)
             wp = packs.get(weight, d, _lib.PACK_FWD)
             if want_stats:
                 rows = query("ur_conv2d_stats_rows", C.byref(d))
                 stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
             with _Timed("igemm_fwd", _conv_flops(d), d):
                 call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight)          # x: as the kernel saw it (channel-padded on the generic path)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -255,11 +287,19 @@ class _Conv2d(Function):
     def backward(ctx, dy, _dstats):
         x, weight = ctx.saved_tensors
         d = ctx.d
+        cout, cin = weight.shape[0], weight.shape[1]
         dy = _g(dy)
         dx = dw = db = None
+        tile_d = use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 1)
+        tile_w = use_tile_kernel and query("ur_wgrad3x3_tile_supported", C.byref(d))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, cout, cout, x.device)
+        if cout % 8 and not (tile_d and tile_w):
+            dy = _pad_channels(dy, _pad8(cout))
+            d = _desc(x.shape, _pad8(cout), d.kh, d.kw, d.stride, d.pad, x.dtype)
         if ctx.needs_input_grad[0]:
             dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
-            if use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 1):
+            if tile_d:
                 wp = ctx.packs.get_tile(weight, d, True)
                 with _Timed("tile_dgrad", _conv_flops(d), d):
                     call("ur_conv3x3_tile_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
@@ -267,9 +307,11 @@ class _Conv2d(Function):
                 wp = ctx.packs.get(weight, d, _lib.PACK_DGRAD)
                 with _Timed("igemm_dgrad", _conv_flops(d), d):
                     call("ur_conv2d_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+            if d.cin != cin:
+                dx = _crop_channels(dx, cin)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            if use_tile_kernel and query("ur_wgrad3x3_tile_supported", C.byref(d)):
+            dw = torch.empty((d.cout, d.cin, d.kh, d.kw), dtype=weight.dtype, device=weight.device)
+            if tile_w:
                 ws = _workspace(query("ur_wgrad3x3_tile_workspace", C.byref(d)), x.device)
                 with _Timed("tile_wgrad", _conv_flops(d), d):
                     call("ur_wgrad3x3_tile", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -279,8 +321,8 @@ class _Conv2d(Function):
                 with _Timed("wgrad", _conv_flops(d), d):
                     call("ur_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
                          C.byref(d), _stream())
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, d.cout, d.cout, x.device)
+            if (d.cout, d.cin) != (cout, cin):
+                dw = dw[:cout, :cin].contiguous()
         return dx, dw, db, None, None, None, None
 
 
@@ -392,8 +434,10 @@ class _BNAct(Function):
             call("ur_bn_eval_prepare", running_mean.data_ptr(), running_var.data_ptr(), c, eps, mean.data_ptr(),
                  invstd.data_ptr(), _stream())
         z = torch.empty_like(y, memory_format=CL)
-        call("ur_bn_act_fwd", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-             _p(residual), act, z.data_ptr(), _dt(y), rows, c, _stream())
+        tb = y.numel() * y.element_size()            # bytes of one pass over the tensor
+        with _Timed("hbm:bn_fwd", tb * (3 if residual is not None else 2)):
+            call("ur_bn_act_fwd", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                 _p(residual), act, z.data_ptr(), _dt(y), rows, c, _stream())
         # the ReLU mask is recomputed from y in backward unless a residual was added before the activation
         ctx.save_for_backward(y, z if (act and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.act, ctx.eval, ctx.has_res = act, not training, residual is not None
@@ -408,8 +452,10 @@ class _BNAct(Function):
         dz = _g(dz)
         nparts = query("ur_bn_stats_rows", rows, c)
         partial = torch.empty((nparts, c, 2), dtype=torch.float32, device=dev)
-        call("ur_bn_act_bwd_reduce", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
-             gamma.data_ptr(), beta.data_ptr(), ctx.act, _dt(y), rows, c, partial.data_ptr(), _stream())
+        tb = y.numel() * y.element_size()
+        with _Timed("hbm:bn_bwd_reduce", tb * (3 if z is not None else 2)):
+            call("ur_bn_act_bwd_reduce", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
+                 gamma.data_ptr(), beta.data_ptr(), ctx.act, _dt(y), rows, c, partial.data_ptr(), _stream())
         sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
@@ -417,9 +463,10 @@ class _BNAct(Function):
              _stream())
         dy = torch.empty_like(y, memory_format=CL)
         dres = torch.empty_like(y, memory_format=CL) if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
-             gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres), _dt(y),
-             rows, c, _stream())
+        with _Timed("hbm:bn_bwd_apply", tb * (3 + (z is not None) + (dres is not None))):
+            call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
+                 gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres),
+                 _dt(y), rows, c, _stream())
         return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
