@@ -185,7 +185,15 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int p = 0; p < nparts; ++p) {
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8) {          // 8 independent loads in flight, summed in row order
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(partial + ((size_t)(p + u) * C + c) * 2);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += v[u].x; s2 += v[u].y; }
+    }
+    for (; p < nparts; ++p) {
         s1 += partial[((size_t)p * C + c) * 2];
         s2 += partial[((size_t)p * C + c) * 2 + 1];
     }
@@ -215,7 +223,15 @@ __global__ void sum_partials_kernel(const float* __restrict__ partial, int npart
     if (c >= C) return;
     for (int k = 0; k < NV; ++k) {
         double s = 0.0;
-        for (int p = 0; p < nparts; ++p) s += partial[((size_t)p * C + c) * NV + k];
+        int p = 0;
+        for (; p + 8 <= nparts; p += 8) {      // 8 independent loads in flight, summed in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[((size_t)(p + u) * C + c) * NV + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < nparts; ++p) s += partial[((size_t)p * C + c) * NV + k];
         if (sums) sums[(size_t)c * NV + k] = (float)s;
         if (k == 0 && o0) o0[c] = (float)s;
         if (k == 1 && o1) o1[c] = (float)s;
@@ -443,10 +459,16 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
 }
 
 // Elementwise grid: enough workgroups to fill the chip several times over, each thread walking EW_UNROLL+ pieces.
-int ew_grid(long long pieces) {
+// The count is rounded down to a multiple of C / gcd(C, NT * 8) when possible, which makes the grid stride a
+// multiple of C (a thread then keeps its channels for the whole walk) for channel counts such as 80 too.
+int ew_grid(long long pieces, int C) {
     long long g = (pieces + (long long)NT * EW_UNROLL - 1) / ((long long)NT * EW_UNROLL);
     if (g < 1) g = 1;
     if (g > 256 * 8) g = 256 * 8;
+    int a = C, b = NT * 8;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int q = C / a;
+    if (g >= q) g -= g % q;
     return (int)g;
 }
 
@@ -533,7 +555,7 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(z) && aligned16(residual) && aligned16(mean) &&
                      aligned16(invstd) && aligned16(gamma) && aligned16(beta);
     if (dtype == UR_BF16 && vec && c % 8 == 0) {
-        const int grid = ew_grid(total / 8);
+        const int grid = ew_grid(total / 8, c);
         const bool fixed = ((long long)grid * NT * 8) % c == 0;
 #define UR_BN_FWD(FIXED, RES)                                                                                             \
     hipLaunchKernelGGL((bn_act_fwd_bf16x8_kernel<FIXED, RES>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)y,  \
@@ -594,7 +616,7 @@ int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const floa
     const bool al = aligned16(dz) && aligned16(y) && aligned16(z) && aligned16(dy) && aligned16(dres);
     if (dtype == UR_BF16 && c % 8 == 0 && al && beta && aligned16(mean) && aligned16(invstd) && aligned16(gamma) &&
         aligned16(beta) && aligned16(sums)) {
-        const int grid = ew_grid(total / 8);
+        const int grid = ew_grid(total / 8, c);
         const bool fixed = ((long long)grid * NT * 8) % c == 0;
         const bool have_z = act && z;
 #define UR_BN_BWD(FIXED, HZ, DR)                                                                                          \
