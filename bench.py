@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="print per-(kernel, shape) conv timings to stderr")
+    ap.add_argument("--per-shape-top", type=int, default=40)
     return ap.parse_args()
 
 
@@ -172,7 +173,7 @@ def main():
             roof["all_conv_mfma_util"] = round(conv_flops / conv_secs / 1e12 / peak, 4)
             roof["all_conv_time_share_of_step"] = round(conv_secs / elapsed, 3)
         if args.per_shape:
-            for (tag, shape), (n, fl, sec) in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:40]:
+            for (tag, shape), (n, fl, sec) in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:args.per_shape_top]:
                 print("%-12s %-34s calls %4d  %8.3f ms/step  %7.1f %s" % (tag, shape, n, sec / args.steps * 1e3, fl / sec / 1e12,
                                                                           "TB/s" if tag.startswith("hbm:") else "TF"), file=sys.stderr)
         cpu = None

@@ -1,0 +1,63 @@
+"""A/B timing of builds of the 3x3 tile kernel: python tools/bench_tile.py a.so b.so ...
+
+Each library must export the ur_conv3x3_tile_* entry points.  Variants are interleaved and the best of three
+rounds (40 launches each after 20 warm-up launches) is kept, so that clock ramps do not bias the comparison.
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import uresnet_amd  # noqa: E402,F401
+from uresnet_amd._lib import ConvDesc, UR_BF16  # noqa: E402
+
+SHAPES = [(6, 256, 512, 128, 128), (6, 256, 512, 64, 64), (6, 64, 128, 512, 512), (6, 512, 1024, 64, 64),
+          (6, 128, 256, 256, 256)]
+
+
+def main():
+    libs = sys.argv[1:]
+    if os.environ.get("TILE_SHAPE"):          # one shape only (hardware-counter runs)
+        SHAPES[:] = [SHAPES[int(os.environ["TILE_SHAPE"])]]
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for (n, h, w, cin, cout) in SHAPES:
+        x = torch.randn(n, h, w, cin, device=dev).relu_().to(torch.bfloat16)
+        wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+        y = torch.empty(n, h, w, cout, device=dev, dtype=torch.bfloat16)
+        d = ConvDesc(UR_BF16, n, h, w, cin, h, w, cout, 3, 3, 1, 1, cin, cout)
+        flops = 2.0 * n * h * w * cin * cout * 9
+        runs, ref = [], None
+        for path in libs:
+            lib = C.CDLL(os.path.abspath(path))
+            lib.ur_conv3x3_tile_packed_elems.restype = C.c_size_t
+            wp = torch.empty(lib.ur_conv3x3_tile_packed_elems(C.byref(d)), device=dev, dtype=torch.bfloat16)
+            lib.ur_conv3x3_tile_pack_weight(C.c_void_p(wt.data_ptr()), C.c_void_p(wp.data_ptr()), C.byref(d), 0, C.c_void_p(st))
+            args = (C.c_void_p(x.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(y.data_ptr()), None, C.byref(d), C.c_void_p(st))
+            assert lib.ur_conv3x3_tile_fwd(*args) == 0
+            out = y.float().clone()
+            if ref is None:
+                ref = out
+            err = float((out - ref).norm() / ref.norm())
+            runs.append((os.path.basename(path), lib, args, wp, err))
+        best = {}
+        for rep in range(3):
+            for name, lib, args, _, _ in runs:
+                for _ in range(20):
+                    lib.ur_conv3x3_tile_fwd(*args)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(40):
+                    lib.ur_conv3x3_tile_fwd(*args)
+                e1.record()
+                torch.cuda.synchronize()
+                best[name] = min(best.get(name, 1e9), e0.elapsed_time(e1) / 40)
+        for name, _, _, _, err in runs:
+            ms = best[name]
+            print("%-28s %-14s %8.1f us  %7.1f TF  rel.diff vs first %.1e" % ((n, h, w, cin, cout), name, ms * 1e3, flops / ms / 1e9, err), flush=True)
+
+
+if __name__ == "__main__":
+    main()

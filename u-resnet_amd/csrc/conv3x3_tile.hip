@@ -3,19 +3,22 @@
 // layers that carry ~94 % of U-ResNet's FLOPs.
 //
 // Workgroup (4 waves) -> 4R x 32 output pixels x 64 output channels, R = 4 (R = 2 for small images).
-// The reduction runs over 16-channel slices of the input.  Per slice the workgroup stages
-//   * the (4R+2) x 34 pixel halo, 32 bytes per pixel; the two 16-byte pieces of a pixel are swapped in every
-//     second group of 8 columns, which makes the 32-consecutive-pixel fragment reads conflict-free and keeps
-//     every row at a constant byte distance (fragment address = per-lane base + immediate),
-//   * the 9 x 64 x 16 weight slice, pre-packed in MFMA-fragment order and copied by LDS-DMA,
-// into one of two LDS stages: loads for slice c+1 are issued before the MFMAs of slice c and the halo is
-// written to the other stage behind two thirds of them; one barrier per slice.
-// Wave w owns output rows [wR, wR+R).  For one horizontal tap offset it reads R+2 halo-row fragments and
-// reuses each for the three vertical taps, and each of the 6 weight fragments for R rows:
-// (R+2) + 6 LDS reads feed 6R v_mfma_f32_32x32x16_bf16 (0.5 reads per MFMA at R = 4).
-// LDS reads are issued by hand (inline assembly, counted s_waitcnt): weight fragments two steps ahead, the row
-// fragments of the next horizontal offset five steps ahead.  Left to itself the compiler sinks every read
-// down to its first use and each group of four MFMAs then waits out a full LDS round trip.
+// The reduction runs over 16-channel slices of the input; two LDS stages alternate, one barrier per slice.
+// A stage holds
+//   * the (4R+2) x 34 pixel halo of the slice, 32 bytes per pixel; the two 16-byte pieces of a pixel are
+//     swapped in every second group of 8 columns, which makes the 32-consecutive-pixel fragment reads
+//     conflict-free and keeps every row at a constant byte distance (fragment address = lane base + immediate),
+//   * the 9 x 64 x 16 weight slice, pre-packed in MFMA-fragment order and copied by LDS-DMA.
+// Halo loads cover two slices at a time: four consecutive lanes fetch the 64 contiguous bytes (32 channels)
+// of a pixel, so one wave-wide load touches 16 cache lines instead of 32 -- with 32-byte pieces the
+// texture-address path, not the MFMA, set the pace.  Lanes 0,1 of a quad own the even slice of the pair and
+// write it to LDS during the odd slice before it; lanes 2,3 own the odd slice and write it one slice later.
+// Wave w owns output rows [wR, wR+R).  For one horizontal tap offset it walks the R+2 halo rows once
+// ("phases"); the fragment of halo row i feeds the MFMAs of every (output row, vertical tap) pair with
+// row + tap = i, and each of the 6 weight fragments serves R rows: (R+2) + 6 LDS reads per 6R MFMAs.
+// LDS reads are issued by hand (inline assembly, counted s_waitcnt) three phases ahead of their MFMAs.
+// Left to itself the compiler sinks every read down to its first use and each group of MFMAs then waits
+// out a full LDS round trip.
 // The epilogue stages the wave's tile in LDS and writes 16-byte pieces (full 128-byte pixel rows).
 #include "ur_common.h"
 #include <cstdlib>
@@ -32,19 +35,18 @@ constexpr int W_GROUPS = W_PIECES / 64;              // one group = one wave-wid
 constexpr int W_GROUP_ITERS = (W_GROUPS + 3) / 4;
 constexpr int W_BYTES = W_PIECES * 16;               // 18432
 constexpr int OUT_PITCH = 144;                       // bytes per staged output pixel (128 + 16: the two half-waves land on disjoint banks)
-constexpr int STEPS = 18;
-constexpr int COMMIT_STEP = 16;                      // step ahead of which the next slice's halo is written (loads had 16 steps to land)
 
 template <int R> struct Geo {
     static constexpr int TH = 4 * R;
     static constexpr int HALO_PIX = (TH + 2) * HALO_W;
-    static constexpr int HALO_PIECES = HALO_PIX * 2;
+    static constexpr int HALO_PIECES = HALO_PIX * 4;               // 16-byte pieces of a 32-channel slice pair
     static constexpr int HALO_ITERS = (HALO_PIECES + NTHREADS - 1) / NTHREADS;
     static constexpr int HALO_BYTES = HALO_PIX * 32;
     static constexpr int STAGE_BYTES = HALO_BYTES + W_BYTES;
     static constexpr int OUT_BYTES = 4 * R * TW * OUT_PITCH;       // epilogue staging, all four waves
     static constexpr int RED_BYTES = 4 * BN * 2 * 4;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES > OUT_BYTES + RED_BYTES ? 2 * STAGE_BYTES : OUT_BYTES + RED_BYTES;
+    static constexpr int DUMP_BYTES = NTHREADS * 16;               // per-lane slots for the halo writes of non-owner lanes
+    static constexpr int LDS_BYTES = (2 * STAGE_BYTES > OUT_BYTES + RED_BYTES ? 2 * STAGE_BYTES : OUT_BYTES + RED_BYTES) + DUMP_BYTES;
 };
 
 struct TileParams {
@@ -57,8 +59,6 @@ struct TileParams {
     int tiles_x, tiles_y, tiles;     // spatial tiles per image row / column / total (N * ty * tx)
     int nblocks;                     // Cout / 64
 };
-
-__device__ __attribute__((aligned(16))) const unsigned int tile_zero_piece[4] = {0u, 0u, 0u, 0u};
 
 // ---- hand-issued LDS traffic ---------------------------------------------------------------------------
 // Asynchronous global -> LDS copy (LDS-DMA): every lane supplies its own 16-byte source, the data land at
@@ -94,18 +94,29 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// LDS operations a wave issues in step t of a slice, in issue order: halo writes, weight fragment t+2, row fragments
-constexpr int ops_write(int t, bool more, int nw) { return (more && t == COMMIT_STEP) ? nw : 0; }
-constexpr int ops_b(int t) { return t + 2 < STEPS ? 1 : 0; }
-constexpr int ops_a(int t, int na) { return (t % 6 == 1 && t / 6 < 2) ? na : 0; }
-constexpr int ops_all(int t, bool more, int nw, int na) { return ops_write(t, more, nw) + ops_b(t) + ops_a(t, na); }
-// operations issued after weight fragment s (issued in step s-2, or ahead of the loop for s < 2) up to the
-// MFMAs of step s: the lgkmcnt value at which fragment s is known to have arrived
-constexpr int younger_than_b(int s, bool more, int nw, int na) {
-    return s == 0 ? 1 + ops_all(0, more, nw, na)
-         : s == 1 ? ops_all(0, more, nw, na) + ops_all(1, more, nw, na)
-                  : ops_a(s - 2, na) + ops_all(s - 1, more, nw, na) + ops_all(s, more, nw, na);
-}
+// Read schedule of one slice.  Phase P = (horizontal offset g = P / NA, halo row i = P % NA) needs the row
+// fragment of halo row i and, in the first three phases of an offset, the two weight fragments of vertical tap i.
+template <int R> struct Sched {
+    static constexpr int NA = R + 2;
+    static constexpr int PH = 3 * NA;
+    static constexpr int LOOK = 3;                         // phases between a read and its MFMAs
+    static constexpr int WS = 5;                           // staging piece j is handled in phase WS + j
+    static constexpr int nreads(int u) { return u >= PH ? 0 : ((u % NA) < 3 ? 3 : 1); }
+    // LDS operations issued after the reads of phase t and before the wait of slot t.  Slot u issues the reads of
+    // phase u + LOOK, waits for those of phase u, then issues its MFMAs with at most one halo write among them.
+    // lgkmcnt holds 4 bits.
+    static constexpr int younger(int t, int nwrites) {
+        int n = 0;
+        for (int u = t + 1; u <= t + LOOK; ++u) n += nreads(u);
+        for (int u = t - LOOK; u < t; ++u) n += (u >= WS && u < WS + nwrites) ? 1 : 0;
+        return n < 15 ? n : 15;
+    }
+    static constexpr int nmfma(int u) {                    // MFMAs of phase u
+        int n = 0;
+        for (int dy = 0; dy < 3; ++dy) n += ((u % NA) - dy >= 0 && (u % NA) - dy < R) ? 2 : 0;
+        return n;
+    }
+};
 
 __device__ __forceinline__ int halo_lds_offset(int hy, int hx, int piece) {
     return hy * ROW_BYTES + hx * 32 + ((piece ^ ((hx >> 3) & 1)) << 4);
@@ -114,7 +125,8 @@ __device__ __forceinline__ int halo_lds_offset(int hy, int hx, int piece) {
 template <int R>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p) {
     using G = Geo<R>;
-    constexpr int NA = R + 2, NW = G::HALO_ITERS;
+    using S = Sched<R>;
+    constexpr int NA = S::NA, NW = G::HALO_ITERS;
     __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
 
     // XCD-aware order: ids congruent mod 8 share an L2; they walk the channel blocks of one spatial tile
@@ -132,48 +144,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
     const unsigned lds0 = (unsigned)(size_t)lds;
 
     // ---- staging bookkeeping: halo pieces this thread owns (fixed for the whole channel loop) -------
-    // Branch-free: surplus threads of the last round repeat the last piece (same value to the same address);
-    // padding pixels read a zero block, so no arithmetic touches the loaded registers before the LDS write.
-    int h_goff[NW];                  // element offset of the piece's pixel (+ 8 * piece), -1 = zero block
-    unsigned h_loff[NW];             // LDS byte address inside stage 0
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-        int i = tid + j * NTHREADS;
-        i = i < G::HALO_PIECES ? i : G::HALO_PIECES - 1;
-        const int pix = i >> 1, piece = i & 1;
-        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-        h_loff[j] = lds0 + halo_lds_offset(hy, hx, piece);
-        h_goff[j] = -1;
-        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-            h_goff[j] = ((img * p.H + gy) * p.W + gx) * p.ld_in + piece * 8;     // < 2^31 (checked on the host)
-    }
-    const int chunks = p.Cin / KC;
+    // Piece i = tid + 256 j covers 8 channels of pixel i >> 2: channels [8 (i & 3), +8) of a 32-channel slice
+    // pair, i.e. piece (i & 1) of slice (i >> 1) & 1 of the pair; i & 3 = tid & 3 for every j.
+    // Branch-free: surplus threads of the last round repeat the last piece of their kind (same value to the same
+    // address).
+    // Nothing per piece is kept in registers (they are needed for accumulators and fragments): offsets are
+    // recomputed from the thread id at every use, and the id is laundered through an empty asm so that the
+    // compiler does not hoist the loop-invariant results back into 20 registers.
+    const int chunks = p.Cin / KC;                 // even: Cin is a multiple of 32
     // weights: 18 groups of 64 pieces (1 KiB); wave w copies groups w, w+4, ... straight into LDS
     const bf16x8_t* wsrc = reinterpret_cast<const bf16x8_t*>(p.wpk) + (size_t)nb * chunks * W_PIECES + lane;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int img_pix0 = img * p.H * p.W;
 
     bf16x8_t ph[NW];
-    auto prefetch = [&](int chunk, unsigned stage_off) {
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const bf16_t* src = h_goff[j] >= 0 ? p.x + (size_t)h_goff[j] + chunk * KC
-                                               : reinterpret_cast<const bf16_t*>(tile_zero_piece);
-            ph[j] = *reinterpret_cast<const bf16x8_t*>(src);
-        }
-        const bf16x8_t* ws = wsrc + (size_t)chunk * W_PIECES;
-        const unsigned wdst = __builtin_amdgcn_readfirstlane(lds0 + stage_off) + G::HALO_BYTES;
-#pragma unroll
-        for (int j = 0; j < W_GROUP_ITERS; ++j) {
-            // the two surplus slots of the last round repeat group 17 (same bytes, same place)
-            int g = wave_u + 4 * j;
-            g = g < W_GROUPS ? g : W_GROUPS - 1;
-            lds_dma16(ws + g * 64, wdst + g * 1024);
+    // Halo coordinates of the thread's pieces, walked without integer division or 32-bit multiplies (both run at
+    // a quarter of the VALU rate, and this code sits between MFMA phases): piece j+1 is 64 pixels = one row and
+    // 30 columns further.  Surplus pieces of the last round fall back to the last halo pixel.
+    struct Walk {
+        int hy, hx;
+        __device__ __forceinline__ void start(int t) { const int pix = t >> 2; hy = pix >= HALO_W ? 1 : 0; hx = pix - hy * HALO_W; }
+        __device__ __forceinline__ void next() {
+            hx += 64 - HALO_W; hy += 1;
+            if (hx >= HALO_W) { hx -= HALO_W; hy += 1; }
+            if (hy >= G::TH + 2) { hy = G::TH + 1; hx = HALO_W - 1; }
         }
     };
-    auto commit = [&](unsigned stage_off) {
-#pragma unroll
-        for (int j = 0; j < NW; ++j) lds_write16<0>(h_loff[j] + stage_off, ph[j]);
+    const int row_elems = p.W * p.ld_in;                                   // < 2^24 (checked on the host)
+    const int off00 = (img_pix0 + (ty0 - 1) * p.W + tx0 - 1) * p.ld_in;    // element offset of halo pixel (0, 0); may be negative
+    // one piece of the pair of slices starting at `chunk` (even); wk = halo pixel of the piece
+    auto load_piece = [&](bf16x8_t& dst, const Walk& wk, int t, int chunk) {
+        const bool ok = (unsigned)(ty0 - 1 + wk.hy) < (unsigned)p.H && (unsigned)(tx0 - 1 + wk.hx) < (unsigned)p.W;
+        // padding pixels load the first element of the tensor (always a valid address) and are zeroed when written
+        // to LDS: no branch, and no arithmetic on the loaded registers while the load is in flight
+        const int off = __mul24(wk.hy, row_elems) + __mul24(wk.hx, p.ld_in) + off00 + (t & 3) * 8 + chunk * KC;   // < 2^31
+        dst = *reinterpret_cast<const bf16x8_t*>(p.x + (ok ? off : 0));
+    };
+    // The lanes that own slices of parity `half` write their piece; the other lanes write theirs to a per-lane
+    // dump slot behind the stages (a select on the address instead of a branch keeps the whole phase one basic
+    // block, so that the scheduler can interleave this arithmetic with the MFMAs).
+    auto write_piece = [&](const bf16x8_t& src, const Walk& wk, int t, int half) {
+        const bool ok = (unsigned)(ty0 - 1 + wk.hy) < (unsigned)p.H && (unsigned)(tx0 - 1 + wk.hx) < (unsigned)p.W;
+        const bf16x8_t v = ok ? src : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned real = lds0 + half * G::STAGE_BYTES + __mul24(wk.hy, ROW_BYTES) + wk.hx * 32 + ((((wk.hx >> 3) ^ t) & 1) << 4);
+        const unsigned dump = lds0 + G::LDS_BYTES - NTHREADS * 16 + t * 16;
+        lds_write16<0>(((t >> 1) & 1) == half ? real : dump, v);
+    };
+    // wave w copies weight groups w, w+4, ... (1 KiB each) of slice `chunk` straight into LDS; the two surplus
+    // slots of the last round repeat group 17 (same bytes, same place)
+    auto dma_group = [&](int chunk, int j) {
+        int g = wave_u + 4 * j;
+        g = g < W_GROUPS ? g : W_GROUPS - 1;
+        lds_dma16(wsrc + (size_t)chunk * W_PIECES + g * 64,
+                  __builtin_amdgcn_readfirstlane(lds0 + (chunk & 1) * G::STAGE_BYTES) + G::HALO_BYTES + g * 1024);
     };
 
     f32x16_t acc[R][2];
@@ -191,45 +214,91 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
     for (int dx = 0; dx < 3; ++dx) a_base[dx] = lds0 + halo_lds_offset(wave * R, lx + dx, lh);
     const unsigned b_base = lds0 + G::HALO_BYTES + lane * 16;
 
-    prefetch(0, 0);
-    commit(0);
+    {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        Walk wk; wk.start(t);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) { load_piece(ph[j], wk, t, 0); wk.next(); }
+#pragma unroll
+        for (int j = 0; j < W_GROUP_ITERS; ++j) dma_group(0, j);
+        wk.start(t);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) { write_piece(ph[j], wk, t, 0); wk.next(); }   // slice 1 stays in the registers of lanes 2,3
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
 
-    // one reduction slice; MORE = another slice follows
-    auto slice = [&](int chunk, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        const unsigned so = (chunk & 1) * G::STAGE_BYTES;          // stage read by this slice
-        const unsigned oo = G::STAGE_BYTES - so;                    // the other one: last read before the previous barrier
-        if constexpr (MORE) prefetch(chunk + 1, oo);
+    // One reduction slice.  ODD = parity of the slice; NEXT = another slice follows;
+    // PAIR = (even slices) another slice pair follows this one, (odd slices) same as NEXT.
+    auto slice = [&](int chunk, auto odd_tag, auto next_tag, auto pair_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value, NEXT = decltype(next_tag)::value, PAIR = decltype(pair_tag)::value;
+        constexpr int NWR = NEXT ? NW : 0;
+        const unsigned so = ODD ? G::STAGE_BYTES : 0;              // stage read by this slice; the other one was last
+                                                                   // read before the previous barrier and is refilled now
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        Walk wk; wk.start(t);
         const unsigned ab[3] = {a_base[0] + so, a_base[1] + so, a_base[2] + so};
         const unsigned bb = b_base + so;
-        bf16x8_t af[2][NA], bq[3];
-        static_for<NA>([&](auto i) { lds_read16<i * ROW_BYTES>(af[0][i], ab[0]); });
-        lds_read16<0>(bq[0], bb);
-        lds_read16<1024>(bq[1], bb);
-        static_for<STEPS>([&](auto S) {
-            constexpr int s = S, dx = s / 6, dy = (s % 6) / 2, b = s & 1;
-            if constexpr (MORE && s == COMMIT_STEP) commit(oo);
-            if constexpr (s + 2 < STEPS) {
-                constexpr int s2 = s + 2, tap2 = ((s2 % 6) / 2) * 3 + s2 / 6;
-                lds_read16<(tap2 * 2 + (s2 & 1)) * 1024>(bq[s2 % 3], bb);
+        bf16x8_t ar[4], br[8];
+        auto issue = [&](auto PP) {                                // reads of phase PP
+            constexpr int P = PP, g = P / NA, i = P % NA;
+            if constexpr (P < S::PH) {
+                lds_read16<i * ROW_BYTES>(ar[P % 4], ab[g]);
+                if constexpr (i < 3) {
+                    lds_read16<((i * 3 + g) * 2 + 0) * 1024>(br[(g * 6 + i * 2 + 0) % 8], bb);
+                    lds_read16<((i * 3 + g) * 2 + 1) * 1024>(br[(g * 6 + i * 2 + 1) % 8], bb);
+                }
             }
-            if constexpr (s % 6 == 1 && dx < 2)
-                static_for<NA>([&](auto i) { lds_read16<i * ROW_BYTES>(af[(dx + 1) & 1][i], ab[dx + 1]); });
-            lds_wait<younger_than_b(s, MORE, NW, NA)>();
+        };
+        static_for<S::LOOK>([&](auto P) { issue(P); });
+        static_for<S::PH>([&](auto PP) {
+            constexpr int P = PP, g = P / NA, i = P % NA;
+            issue(std::integral_constant<int, P + S::LOOK>{});
+            lds_wait<S::younger(P, NWR)>();
             __builtin_amdgcn_sched_barrier(0);
+            // staging for the next slice, one piece per phase: weight groups by LDS-DMA, then halo pieces to the
+            // other stage; even slices refill the freed registers
+            constexpr bool STAGE = NEXT && P >= S::WS && P < S::WS + NW;
+            if constexpr (NEXT && P < W_GROUP_ITERS) dma_group(chunk + 1, P);
+            if constexpr (STAGE) {
+                write_piece(ph[P - S::WS], wk, t, ODD ? 0 : 1);
+                if constexpr (!ODD && PAIR) load_piece(ph[P - S::WS], wk, t, chunk + 2);
+                wk.next();
+            }
 #pragma unroll
-            for (int a = 0; a < R; ++a)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dx & 1][a + dy], bq[s % 3], acc[a][b], 0, 0, 0);
+            for (int dy = 0; dy < 3; ++dy) {
+                const int a = i - dy;
+                if (a >= 0 && a < R) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[P % 4], br[(g * 6 + dy * 2 + b) % 8], acc[a][b], 0, 0, 0);
+                }
+            }
+            if constexpr (STAGE) {
+                // interleave: the piece's address arithmetic (about 30 VALU instructions) issues under the MFMAs
+                static_for<S::nmfma(P)>([&](auto) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                });
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // this wave's LDS-DMA pieces and halo writes have landed; then everybody's
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        // this wave's LDS-DMA pieces and halo writes have landed (the halo loads just issued stay in flight)
+        if constexpr (!ODD && PAIR) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
-    for (int chunk = 0; chunk + 1 < chunks; ++chunk) slice(chunk, std::true_type{});
-    slice(chunks - 1, std::false_type{});
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int chunk = 0;
+    for (; chunk + 2 < chunks; chunk += 2) {
+        slice(chunk, F_{}, T_{}, T_{});
+        slice(chunk + 1, T_{}, T_{}, T_{});
+    }
+    slice(chunk, F_{}, T_{}, F_{});
+    slice(chunk + 1, T_{}, F_{}, F_{});
 
     // ---- epilogue: per-channel partial statistics of the fp32 results, bf16 tile via LDS -> 16-byte stores ----
     unsigned char* ostage = lds + wave * (R * TW * OUT_PITCH);
@@ -309,11 +378,13 @@ int check(const ur_conv_desc* d, bool dgrad) {
     UR_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w,
                "conv3x3_tile: 3x3 stride 1 pad 1 only");
     const int rows = dgrad ? d->cin : d->cout, red = dgrad ? d->cout : d->cin;
-    UR_REQUIRE(rows % BN == 0 && red % KC == 0, "conv3x3_tile: needs %d | produced channels and %d | reduced channels",
-               BN, KC);
+    UR_REQUIRE(rows % BN == 0 && red % (2 * KC) == 0, "conv3x3_tile: needs %d | produced channels and %d | reduced channels",
+               BN, 2 * KC);
     UR_REQUIRE(d->in_ld % 8 == 0 && d->out_ld % 8 == 0, "conv3x3_tile: pitches must be multiples of 8");
     UR_REQUIRE((long long)d->n * d->h * d->w * (d->in_ld > d->out_ld ? d->in_ld : d->out_ld) < (1LL << 31),
                "conv3x3_tile: tensor exceeds 2^31 elements");
+    UR_REQUIRE((long long)d->w * (d->in_ld > d->out_ld ? d->in_ld : d->out_ld) < (1LL << 24),
+               "conv3x3_tile: an image row exceeds 2^24 elements");
     return UR_OK;
 }
 
@@ -351,8 +422,9 @@ int ur_conv3x3_tile_supported(const ur_conv_desc* d, int dgrad) {
     if (!d || d->dtype != UR_BF16) return 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w)) return 0;
     const int rows = dgrad ? d->cin : d->cout, red = dgrad ? d->cout : d->cin;
-    if (rows % BN != 0 || red % KC != 0 || d->in_ld % 8 != 0 || d->out_ld % 8 != 0) return 0;
+    if (rows % BN != 0 || red % (2 * KC) != 0 || d->in_ld % 8 != 0 || d->out_ld % 8 != 0) return 0;
     if ((long long)d->n * d->h * d->w * (d->in_ld > d->out_ld ? d->in_ld : d->out_ld) >= (1LL << 31)) return 0;
+    if ((long long)d->w * (d->in_ld > d->out_ld ? d->in_ld : d->out_ld) >= (1LL << 24)) return 0;
     return 1;
 }
 
