@@ -374,6 +374,62 @@ def conv_transpose2x2(x, weight, bias, packs):
     return _ConvT2x2.apply(x, weight, bias, packs)
 
 
+class _ConvT2x2Cat(Function):
+    """torch.cat([skip, conv_transpose2x2(x)], dim=1) for equal spatial sizes (S/C:119-124 without padding).
+
+    The transposed convolution scatters straight into the channel window [cs, cs+cout) of the concatenated
+    tensor (the kernels take a channel pitch), and its backward kernels read the matching window of the incoming
+    gradient in place: one copy per direction (the skip half) instead of two.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packs, skip):
+        _require_gpu(x)
+        cin, cout, kh, kw = weight.shape
+        n, _, h, w = x.shape
+        cs = skip.shape[1]
+        d = _desc(x.shape, cout, 2, 2, 2, 0, x.dtype, oh=2 * h, ow=2 * w)
+        d.out_ld = cs + cout
+        wp = packs.get(weight, d, _lib.PACK_CONVT_FWD)
+        out = empty_nhwc(n, cs + cout, 2 * h, 2 * w, x.dtype, x.device)
+        with _Timed("igemm_fwd", _conv_flops(d, True), d):
+            call("ur_convT2x2_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), out.data_ptr() + cs * out.element_size(),
+                 C.byref(d), _stream())
+        _copy_channels(skip, 0, cs, out, 0)
+        ctx.save_for_backward(x, weight)
+        ctx.d, ctx.packs, ctx.has_bias, ctx.cs = d, packs, bias is not None, cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        d, cs = ctx.d, ctx.cs
+        g = _g(g)
+        dy_ptr = g.data_ptr() + cs * g.element_size()
+        dx = dw = db = dskip = None
+        if ctx.needs_input_grad[0]:
+            wp = ctx.packs.get(weight, d, _lib.PACK_CONVT_DGRAD)
+            dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
+            with _Timed("igemm_dgrad", _conv_flops(d, True), d):
+                call("ur_convT2x2_dgrad", dy_ptr, wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            ws = _workspace(query("ur_convT2x2_wgrad_workspace", C.byref(d)), x.device)
+            with _Timed("wgrad", _conv_flops(d, True), d):
+                call("ur_convT2x2_wgrad", x.data_ptr(), dy_ptr, dw.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(d), _stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy_ptr, d.dtype, d.n * d.oh * d.ow, d.cout, d.out_ld, x.device)
+        if ctx.needs_input_grad[4]:
+            dskip = empty_nhwc(d.n, cs, d.oh, d.ow, g.dtype, g.device)
+            _copy_channels(g, 0, cs, dskip, 0)
+        return dx, dw, db, None, dskip
+
+
+def conv_transpose2x2_cat(x, weight, bias, packs, skip):
+    """cat([skip, conv_transpose2x2(x)], dim=1); skip must have exactly twice x's height and width."""
+    return _ConvT2x2Cat.apply(x, weight, bias, packs, skip)
+
+
 class _GConv3x3(Function):
     """Grouped 3x3, stride 1, pad 1, with 1 or 4 channels per group."""
 
