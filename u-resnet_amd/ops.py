@@ -105,10 +105,27 @@ def as_activation(x, dtype):
     return _ToNHWC.apply(x, dtype)
 
 
+def _channel_pitch(x):
+    """Channel pitch of an NHWC tensor whose pixels are `pitch` elements apart (a channel window of a wider
+    dense NHWC tensor), or 0 if x is not of that form."""
+    n, c, h, w = x.shape
+    s = x.stride()
+    ld = s[3]
+    if s[1] == 1 and ld >= c and s[2] == w * ld and s[0] == h * w * ld:
+        return ld
+    return 0
+
+
 def _g(g):
-    """Incoming gradient -> dense NHWC tensor (autograd may hand over NCHW or expanded tensors)."""
+    """Incoming gradient -> dense NHWC tensor (autograd may hand over NCHW, expanded or channel-window tensors)."""
     if _is_nhwc_dense(g):
         return g
+    ld = _channel_pitch(g)
+    if ld and g.is_cuda and g.dtype in _DT:
+        n, c, h, w = g.shape
+        y = empty_nhwc(n, c, h, w, g.dtype, g.device)
+        call("ur_copy_channels", g.data_ptr(), ld, 0, h, w, y.data_ptr(), c, 0, h, w, 0, 0, n, c, _dt(g), _stream())
+        return y
     return to_nhwc_raw(g.contiguous(), g.dtype)
 
 
@@ -420,8 +437,9 @@ class _ConvT2x2Cat(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy_ptr, d.dtype, d.n * d.oh * d.ow, d.cout, d.out_ld, x.device)
         if ctx.needs_input_grad[4]:
-            dskip = empty_nhwc(d.n, cs, d.oh, d.ow, g.dtype, g.device)
-            _copy_channels(g, 0, cs, dskip, 0)
+            # a channel window of g, not a copy: the skip tensor has a second consumer, so autograd adds this to
+            # the other gradient in one pass; a lone consumer densifies it through _g()
+            dskip = g[:, :cs]
         return dx, dw, db, None, dskip
 
 
