@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
         const bool ok = (unsigned)(ty0 - 1 + wk.hy) < (unsigned)p.H && (unsigned)(tx0 - 1 + wk.hx) < (unsigned)p.W;
         // padding pixels load the first element of the tensor (always a valid address) and are zeroed when written
         // to LDS: no branch, and no arithmetic on the loaded registers while the load is in flight
-        const int off = __mul24(wk.hy, row_elems) + __mul24(wk.hx, p.ld_in) + off00 + (t & 3) * 8 + chunk * KC;   // < 2^31
+        const int off = (int)__umul24(wk.hy, row_elems) + (int)__umul24(wk.hx, p.ld_in) + off00 + (t & 3) * 8 + chunk * KC;   // < 2^31
         dst = *reinterpret_cast<const bf16x8_t*>(p.x + (ok ? off : 0));
     };
     // The lanes that own slices of parity `half` write their piece; the other lanes write theirs to a per-lane
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
     auto write_piece = [&](const bf16x8_t& src, const Walk& wk, int t, int half) {
         const bool ok = (unsigned)(ty0 - 1 + wk.hy) < (unsigned)p.H && (unsigned)(tx0 - 1 + wk.hx) < (unsigned)p.W;
         const bf16x8_t v = ok ? src : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        const unsigned real = lds0 + half * G::STAGE_BYTES + __mul24(wk.hy, ROW_BYTES) + wk.hx * 32 + ((((wk.hx >> 3) ^ t) & 1) << 4);
+        const unsigned real = lds0 + half * G::STAGE_BYTES + __umul24(wk.hy, ROW_BYTES) + wk.hx * 32 + ((((wk.hx >> 3) ^ t) & 1) << 4);
         const unsigned dump = lds0 + G::LDS_BYTES - NTHREADS * 16 + t * 16;
         lds_write16<0>(((t >> 1) & 1) == half ? real : dump, v);
     };

@@ -15,6 +15,7 @@
 // (2 x BN/32 accumulator tiles of 32x32).  One LDS buffer, register prefetch of the next
 // k-slice while the current one is multiplied.
 #include "ur_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -85,7 +86,7 @@ __device__ __forceinline__ bool tap_source(const IgemmParams& p, int oy, int ox,
     return iy < p.H && ix < p.W;
 }
 
-template <typename T, int BN, bool VEC8>
+template <typename T, int BN, bool VEC8, bool FAST>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmParams p) {
     constexpr int PITCH = LdsPitch<T>::elems;
     constexpr int NT = BN / 32;
@@ -122,6 +123,24 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmParams p) {
             r_img[i] = -1; r_y[i] = 0; r_x[i] = 0;
         }
     }
+    // FAST (vector gather, 32-bit element offsets, stride 1 or 2): the gather runs once per 8-32 MFMAs, so it must not
+    // divide or use 32-bit multiplies (quarter-rate VALU).  Per row: the coordinates and element offset of tap (0, 0);
+    // per thread: the tap (ky, kx) and channel of its 8-wide k chunk, advanced by 32 k per slice with carries.
+    int f_y0[AROWS], f_x0[AROWS], f_off0[AROWS];
+    int f_k = (tid & 3) * 8, f_ky = 0, f_kx = 0, f_ci = 0;
+    unsigned f_ok = 0;
+    const int f_row = p.W * p.src_ld;                    // < 2^24 (checked on the host)
+    if constexpr (FAST) {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            if (p.mode == 0) { f_y0[i] = r_y[i] * p.stride - p.pad; f_x0[i] = r_x[i] * p.stride - p.pad; }
+            else { f_y0[i] = r_y[i] + p.pad; f_x0[i] = r_x[i] + p.pad; }
+            f_off0[i] = r_img[i] * p.H * p.W * p.src_ld;     // image base; the tap term is added per slice
+        }
+        const int tap = f_k / p.C;
+        f_ci = f_k - tap * p.C;
+        f_ky = tap / p.kw; f_kx = tap - f_ky * p.kw;
+    }
     constexpr int BCH = (BN * 4 + NTHREADS - 1) / NTHREADS;   // 16-byte-equivalent B chunks per thread
 
     Vec8<T> pa[AROWS];
@@ -129,7 +148,32 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmParams p) {
     Vec8<T> pb[BCH];
 
     auto gather = [&](int kt) {
-        if constexpr (VEC8) {
+        if constexpr (VEC8 && FAST) {
+            const bool kin = f_k < p.Kred;
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+                int iy, ix;
+                bool ok;
+                if (p.mode == 0) {
+                    iy = f_y0[i] + f_ky; ix = f_x0[i] + f_kx;
+                    ok = true;
+                } else {
+                    const int ty = f_y0[i] - f_ky, tx = f_x0[i] - f_kx;
+                    if (p.stride == 1) { iy = ty; ix = tx; ok = true; }
+                    else { iy = ty >> 1; ix = tx >> 1; ok = ((ty | tx) & 1) == 0; }      // stride 2
+                }
+                ok = ok && kin && r_img[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const int off = f_off0[i] + (int)__umul24(iy, f_row) + (int)__umul24(ix, p.src_ld) + f_ci;
+                pa[i].load(src + (ok ? off : 0));                 // element 0 is always a valid address;
+                f_ok = ok ? (f_ok | (1u << i)) : (f_ok & ~(1u << i));   // zeroed when written to LDS, not while in flight
+            }
+            // advance this thread's k chunk by one slice
+            f_k += BK; f_ci += BK;
+#pragma unroll
+            for (int w = 0; w < BK / 8; ++w) {
+                if (f_ci >= p.C) { f_ci -= p.C; if (++f_kx == p.kw) { f_kx = 0; ++f_ky; } }
+            }
+        } else if constexpr (VEC8) {
             const int k0 = kt * BK + (tid & 3) * 8;
             const bool kin = k0 < p.Kred;
             int tap = 0, ci = 0, ky = 0, kx = 0;
@@ -171,7 +215,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmParams p) {
     auto commit = [&]() {
         if constexpr (VEC8) {
 #pragma unroll
-            for (int i = 0; i < AROWS; ++i) pa[i].store(&As[((tid >> 2) + 64 * i) * PITCH + (tid & 3) * 8]);
+            for (int i = 0; i < AROWS; ++i) {
+                if constexpr (FAST) { if (!((f_ok >> i) & 1)) pa[i].zero(); }
+                pa[i].store(&As[((tid >> 2) + 64 * i) * PITCH + (tid & 3) * 8]);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < BK; ++j) As[tid * PITCH + j] = ur_from_float<T>(pa_s[j]);
@@ -405,14 +452,21 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
     constexpr int VE = 16 / (int)sizeof(T);
     p.vec_store = (p.dst_ld % VE == 0) && (p.Ncols % VE == 0) && ((uintptr_t)p.dst % 16 == 0) &&
                   (!p.scatter || p.cout_t % VE == 0);
-    if (vec) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, true>), dim3(grid), dim3(NTHREADS), 0, st, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, false>), dim3(grid), dim3(NTHREADS), 0, st, p);
+    const bool fast = vec && (p.stride == 1 || p.stride == 2) && (long long)p.N * p.H * p.W * p.src_ld < (1LL << 31) &&
+                      (long long)p.W * p.src_ld < (1LL << 24) && p.H < (1 << 22) && p.kh * p.kw < 4096;
+    if (vec && fast) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, true, true>), dim3(grid), dim3(NTHREADS), 0, st, p);
+    else if (vec) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, true, false>), dim3(grid), dim3(NTHREADS), 0, st, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, false, false>), dim3(grid), dim3(NTHREADS), 0, st, p);
     return ur_check_launch("conv_igemm");
 }
 
 template <typename T>
 int dispatch_igemm(IgemmParams& p, hipStream_t st) {
-    if (p.Ncols > 64) return launch_igemm<T, 128>(p, st);
+    // 128-column tiles need 256 VGPRs (one workgroup per CU, nothing to overlap its barriers with) and measured
+    // 10-25 % slower than 64-column tiles (three workgroups per CU; the extra column tiles re-read A from L2) on every
+    // wide layer of the network; URESNET_IGEMM_BN128=1 selects them for A/B runs
+    static const bool bn128 = [] { const char* e = getenv("URESNET_IGEMM_BN128"); return e && e[0] == '1'; }();
+    if (p.Ncols > 64 && bn128) return launch_igemm<T, 128>(p, st);
     if (p.Ncols > 32) return launch_igemm<T, 64>(p, st);
     return launch_igemm<T, 32>(p, st);
 }
