@@ -87,7 +87,46 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
     int nstages = (p.P + BK - 1) / BK - stage0;
     if (nstages > p.stages_per_split) nstages = p.stages_per_split;
 
+    // The gather runs once per 16 MFMAs, so the common case avoids integer division and 32-bit multiplies (quarter-rate
+    // VALU): when a row of dV is at least BK pixels wide and element offsets fit 32 bits, every loader slot keeps its
+    // pixel coordinates and advances them by BK pixels per stage with at most one carry per dimension.
+    const bool fast = p.OW >= BK && (long long)p.N * p.H * p.W * p.u_ld < (1LL << 31) && (long long)p.P * p.dv_ld < (1LL << 31) &&
+                      (long long)p.W * p.u_ld < (1LL << 24) && p.H < (1 << 22);
+    int fa_off[APASS], fb_img[BPASS], fb_oy[BPASS], fb_ox[BPASS], fa_pix[APASS], fb_pix[BPASS];
+    const int u_row = p.W * p.u_ld, u_img = p.H * p.W * p.u_ld;
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            fa_pix[i] = stage0 * BK + a_row + i * AROWS_PER_PASS;
+            fa_off[i] = fa_pix[i] * p.dv_ld + o0 + a_col;
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int pix = stage0 * BK + b_row + i * BROWS_PER_PASS;
+            fb_pix[i] = pix;
+            const int img = pix / (p.OH * p.OW), rem = pix - img * (p.OH * p.OW);
+            fb_img[i] = img * u_img; fb_oy[i] = rem / p.OW; fb_ox[i] = rem - fb_oy[i] * p.OW;
+        }
+    }
     auto gather = [&](int st) {
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                if (a_ok && fa_pix[i] < p.P) pa[i].load(DV + fa_off[i]);
+                else pa[i].zero();
+                fa_pix[i] += BK; fa_off[i] += BK * p.dv_ld;
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int iy = fb_oy[i] * p.stride + b_ky - p.pad, ix = fb_ox[i] * p.stride + b_kx - p.pad;
+                const bool ok = b_ok && fb_pix[i] < p.P && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                if (ok) pb[i].load(U + (fb_img[i] + (int)__umul24(iy, u_row) + (int)__umul24(ix, p.u_ld) + b_ci));
+                else pb[i].zero();
+                fb_pix[i] += BK; fb_ox[i] += BK;
+                if (fb_ox[i] >= p.OW) { fb_ox[i] -= p.OW; if (++fb_oy[i] == p.OH) { fb_oy[i] = 0; fb_img[i] += u_img; } }
+            }
+            return;
+        }
         const int pix0 = (stage0 + st) * BK;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
