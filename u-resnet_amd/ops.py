@@ -295,6 +295,7 @@ class _Conv2d(Function):
                 call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
         ctx.save_for_backward(x, weight)          # x: as the kernel saw it (channel-padded on the generic path)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
+        ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -302,6 +303,8 @@ class _Conv2d(Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         d = ctx.d
         cout, cin = weight.shape[0], weight.shape[1]
