@@ -136,9 +136,12 @@ int ur_bn_finalize(float* partial, int nparts, long long count, int c, float eps
 /* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
 int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int c, float eps, float* mean,
                        float* invstd, ur_stream_t s);
-/* z = act((y-mean)*invstd*gamma + beta (+ residual));  act: 0 none, 1 relu */
+/* z = act((y-mean)*invstd*gamma + beta (+ residual));  act: 0 none, 1 relu.  z_ld = channel pitch of z in
+ * elements (0 or c: dense); a larger pitch writes into a channel window of a wider NHWC tensor (the skip half
+ * of a torch.cat, S/C:119-124) */
 int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  const void* residual, int act, void* z, int dtype, long long rows, int c, ur_stream_t s);
+                  const void* residual, int act, void* z, int dtype, long long rows, int c, int z_ld,
+                  ur_stream_t s);
 /* backward pass 1: partial[nparts][c][2] = (sum g, sum g*xhat), g = dz masked by the ReLU (act != 0).
  * The mask comes from the saved output z when z != NULL, else it is recomputed from y (needs gamma, beta;
  * valid only when no residual was added before the activation). */
@@ -157,7 +160,9 @@ int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const floa
 /* ---------------------------------------------------------------- spatial ops
  * MaxPool2d(2,2) (S/C:105), bilinear Upsample(scale, align_corners=False) (S/C:43,66,362;
  * C/C:303), F.avg_pool2d(k) (C/C:572), F.pad + torch.cat (S/C:121-124, S/C:280). */
-int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, int h, int w, int c, ur_stream_t s);
+/* x_ld: channel pitch of x in elements (0 or c: dense) -- x may be a channel window of a wider NHWC tensor */
+int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, int h, int w, int c, int x_ld,
+                      ur_stream_t s);
 int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int n, int h, int w, int c,
                       ur_stream_t s);
 int ur_upsample_bilinear_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c, int scale,

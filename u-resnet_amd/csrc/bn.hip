@@ -245,14 +245,19 @@ template <typename T>
 __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const T* __restrict__ res, int act,
-                                                        T* __restrict__ z, long long total, int C) {
+                                                        T* __restrict__ z, long long total, int C, int z_ld) {
     // C % 4 == 0 (checked on the host): a float4 / bf16x4 never straddles a row
     const long long stride = (long long)gridDim.x * NT * 4;
     const int cstep = (int)(stride % C);          // channel offset advances mod C: no 64-bit division in the loop
-    int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 4) % C);
-    for (long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 4; i < total; i += stride) {
+    const long long zstep = (stride / C) * z_ld + cstep;           // z may be a channel window: rows are z_ld apart
+    const long long i0 = (blockIdx.x * (long long)NT + threadIdx.x) * 4;
+    int cnext = (int)(i0 % C);
+    long long zoff = (i0 / C) * z_ld + cnext;
+    for (long long i = i0; i < total; i += stride) {
         const int c = cnext;
-        cnext += cstep; if (cnext >= C) cnext -= C;
+        const long long zi = zoff;
+        cnext += cstep; zoff += zstep;
+        if (cnext >= C) { cnext -= C; zoff += z_ld - C; }
         float4 v = ur_load4(y + i);
         float4 m = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
         float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const T* __restrict__ y,
         o.z = (v.z - m.z) * is.z * g.z + b.z; o.w = (v.w - m.w) * is.w * g.w + b.w;
         if (res) { float4 r = ur_load4(res + i); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         if (act) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        ur_store4(z + i, o);
+        ur_store4(z + zi, o);
     }
 }
 
@@ -290,13 +295,17 @@ template <bool FIXED, bool RES>
 __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __restrict__ y, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const bf16_t* __restrict__ res,
-                                                               int act, bf16_t* __restrict__ z, long long total, int C) {
+                                                               int act, bf16_t* __restrict__ z, long long total, int C,
+                                                               int z_ld) {
     const long long stride = (long long)gridDim.x * NT * 8;
     const int cstep = (int)(stride % C);
-    int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 8) % C);
+    const long long zstep = (stride / C) * z_ld + cstep;           // z may be a channel window: rows are z_ld apart
+    long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8;
+    int cnext = (int)(i % C);
+    long long zoff = (i / C) * z_ld + cnext;
     Chan8 k;
     if (FIXED) k.load(mean, invstd, gamma, beta, cnext);
-    auto one = [&](const bf16x8_t& y8, const bf16x8_t& r8, long long i) {
+    auto one = [&](const bf16x8_t& y8, const bf16x8_t& r8, long long zi) {
         bf16x8_t o8;
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
@@ -305,11 +314,10 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __r
             if (act) o = fmaxf(o, 0.f);
             o8[v] = (bf16_t)o;
         }
-        *reinterpret_cast<bf16x8_t*>(z + i) = o8;
+        *reinterpret_cast<bf16x8_t*>(z + zi) = o8;
     };
-    long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8;
     if (FIXED) {
-        for (; i + (EW_UNROLL - 1) * stride < total; i += EW_UNROLL * stride) {
+        for (; i + (EW_UNROLL - 1) * stride < total; i += EW_UNROLL * stride, zoff += EW_UNROLL * zstep) {
             bf16x8_t y8[EW_UNROLL], r8[EW_UNROLL];
 #pragma unroll
             for (int u = 0; u < EW_UNROLL; ++u) {
@@ -317,18 +325,21 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __r
                 if (RES) r8[u] = *reinterpret_cast<const bf16x8_t*>(res + i + u * stride); else r8[u] = y8[u];
             }
 #pragma unroll
-            for (int u = 0; u < EW_UNROLL; ++u) one(y8[u], r8[u], i + u * stride);
+            for (int u = 0; u < EW_UNROLL; ++u) one(y8[u], r8[u], zoff + u * zstep);
         }
     }
     for (; i < total; i += stride) {
+        const long long zi = zoff;
+        zoff += zstep;
         if (!FIXED) {
             k.load(mean, invstd, gamma, beta, cnext);
-            cnext += cstep; if (cnext >= C) cnext -= C;
+            cnext += cstep;
+            if (cnext >= C) { cnext -= C; zoff += z_ld - C; }
         }
         const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
         bf16x8_t r8 = y8;
         if (RES) r8 = *reinterpret_cast<const bf16x8_t*>(res + i);
-        one(y8, r8, i);
+        one(y8, r8, zi);
     }
 }
 
@@ -337,13 +348,14 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_scalar_kernel(const T* __restri
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const T* __restrict__ res, int act, T* __restrict__ z,
-                                                               long long total, int C) {
+                                                               long long total, int C, int z_ld) {
     for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
         const int c = (int)(i % C);
+        const long long zi = (i / C) * z_ld + c;
         float o = (ur_to_float(y[i]) - mean[c]) * invstd[c] * gamma[c] + beta[c];
         if (res) o += ur_to_float(res[i]);
         if (act) o = fmaxf(o, 0.f);
-        z[i] = ur_from_float<T>(o);
+        z[zi] = ur_from_float<T>(o);
     }
 }
 
@@ -549,17 +561,19 @@ int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int 
 }
 
 int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  const void* residual, int act, void* z, int dtype, long long rows, int c, ur_stream_t s) {
+                  const void* residual, int act, void* z, int dtype, long long rows, int c, int z_ld, ur_stream_t s) {
     UR_REQUIRE(y && mean && invstd && gamma && beta && z && rows > 0 && c > 0, "bn_act_fwd: bad arguments");
+    if (z_ld == 0) z_ld = c;
+    UR_REQUIRE(z_ld >= c, "bn_act_fwd: output pitch %d smaller than the channel count %d", z_ld, c);
     const long long total = rows * c;
-    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(z) && aligned16(residual) && aligned16(mean) &&
+    const bool vec = (c % 4 == 0) && (z_ld % (dtype == UR_BF16 ? 8 : 4) == 0) && aligned16(y) && aligned16(z) && aligned16(residual) && aligned16(mean) &&
                      aligned16(invstd) && aligned16(gamma) && aligned16(beta);
     if (dtype == UR_BF16 && vec && c % 8 == 0) {
         const int grid = ew_grid(total / 8, c);
         const bool fixed = ((long long)grid * NT * 8) % c == 0;
 #define UR_BN_FWD(FIXED, RES)                                                                                             \
     hipLaunchKernelGGL((bn_act_fwd_bf16x8_kernel<FIXED, RES>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)y,  \
-                       mean, invstd, gamma, beta, (const bf16_t*)residual, act, (bf16_t*)z, total, c)
+                       mean, invstd, gamma, beta, (const bf16_t*)residual, act, (bf16_t*)z, total, c, z_ld)
         if (fixed) { if (residual) UR_BN_FWD(true, true); else UR_BN_FWD(true, false); }
         else { if (residual) UR_BN_FWD(false, true); else UR_BN_FWD(false, false); }
 #undef UR_BN_FWD
@@ -567,9 +581,9 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
     }
     UR_DISPATCH_DTYPE(dtype, {
         if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(ur_grid_1d(total / 4, NT)), dim3(NT), 0, (hipStream_t)s,
-                                    (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c);
+                                    (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c, z_ld);
         else hipLaunchKernelGGL((bn_act_fwd_scalar_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0, (hipStream_t)s,
-                                (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c);
+                                (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c, z_ld);
     });
     return ur_check_launch("bn_act_fwd");
 }

@@ -32,7 +32,8 @@ template <typename T, int V> struct Pack {
 // ------------------------------------------------------------------ max pool 2x2 stride 2
 template <typename T, int V>
 __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                         uint8_t* __restrict__ idx, int N, int H, int W, int C) {
+                                                         uint8_t* __restrict__ idx, int N, int H, int W, int C, int LD) {
+    // LD: channel pitch of x (x may be a channel window of a wider tensor); y and idx are dense
     const int OH = H / 2, OW = W / 2, CV = C / V;
     const unsigned total = (unsigned)N * OH * OW * CV;
     GRID_STRIDE(i, total) {
@@ -41,9 +42,9 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
         int ox = (int)(pix % OW);
         unsigned t = pix / OW;
         int oy = (int)(t % OH), n = (int)(t / OH);
-        const T* base = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * C + cv * V;
+        const T* base = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * LD + cv * V;
         Pack<T, V> a, b, c, d, o;
-        a.load(base); b.load(base + C); c.load(base + (long long)W * C); d.load(base + (long long)W * C + C);
+        a.load(base); b.load(base + LD); c.load(base + (long long)W * LD); d.load(base + (long long)W * LD + LD);
         uint8_t sel[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -335,12 +336,14 @@ int esize(int dtype) { return dtype == UR_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, int h, int w, int c, ur_stream_t s) {
+int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, int h, int w, int c, int x_ld, ur_stream_t s) {
     UR_REQUIRE(x && y && idx && n > 0 && h >= 2 && w >= 2 && c > 0, "maxpool_fwd: bad arguments");
-    const bool vec = c % 4 == 0 && al(x, 4 * esize(dtype)) && al(y, 4 * esize(dtype));
+    if (x_ld == 0) x_ld = c;
+    UR_REQUIRE(x_ld >= c, "maxpool_fwd: input pitch %d smaller than the channel count %d", x_ld, c);
+    const bool vec = c % 4 == 0 && x_ld % 4 == 0 && al(x, 4 * esize(dtype)) && al(y, 4 * esize(dtype));
     const long long total = (long long)n * (h / 2) * (w / 2) * c;
     UR_REQUIRE_32BIT(total, "maxpool_fwd");
-    SPATIAL_LAUNCH(maxpool_fwd_kernel, total, (const T*)x, (T*)y, idx, n, h, w, c);
+    SPATIAL_LAUNCH(maxpool_fwd_kernel, total, (const T*)x, (T*)y, idx, n, h, w, c, x_ld);
     return ur_check_launch("maxpool_fwd");
 }
 

@@ -36,11 +36,12 @@ def act_layer(act, inplace=False, neg_slope=0.2, n_prelu=1):
     raise NotImplementedError('activation layer [%s] is not found' % act)
 
 
-def _cba(seq, x, i):
-    """Run seq[i] (conv), seq[i+1] (BN), seq[i+2] (activation) fused when the activation is ReLU."""
+def _cba(seq, x, i, out=None):
+    """Run seq[i] (conv), seq[i+1] (BN), seq[i+2] (activation) fused when the activation is ReLU.  `out`: optional
+    channel window for the result (honoured on the fused path only; callers compare data_ptr())."""
     conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
     if type(act) in _ACT_CODES:
-        return conv_bn_act(x, conv, bn, _ACT_CODES[type(act)])
+        return conv_bn_act(x, conv, bn, _ACT_CODES[type(act)], out=out)
     return act(conv_bn_act(x, conv, bn, _lib.ACT_NONE))
 
 
@@ -125,11 +126,11 @@ class DoubleConv(hnn.Sequential):
             hnn.BatchNorm2d(out_channels),
             hnn.ReLU(inplace=True))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         x = ops.as_activation(x, act_dtype(x))
         if has_hooks(*self):
             return super().forward(x)
-        return _cba(self, _cba(self, x, 0), 3)
+        return _cba(self, _cba(self, x, 0), 3, out)
 
 
 class Down(hnn.Sequential):
@@ -147,12 +148,15 @@ class Up(hnn.Module):
         self.up = hnn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
         self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2):
+    def forward(self, x1, x2, cat=None):
+        """cat: the pre-allocated concatenated tensor whose first channel window already holds x2 (x2 is then
+        an alias of that window, see unet_branch_forward)."""
         if not has_hooks(self.up) and x2.shape[2] == 2 * x1.shape[2] and x2.shape[3] == 2 * x1.shape[3]:
             # the transposed convolution writes straight into its half of the concatenated tensor
             x1 = ops.as_activation(x1, act_dtype(x1))
-            x2 = ops.as_activation(x2, x1.dtype)
-            return self.conv(ops.conv_transpose2x2_cat(x1, self.up.weight, self.up.bias, self.up._packs, x2))
+            if cat is None:
+                x2 = ops.as_activation(x2, x1.dtype)
+            return self.conv(ops.conv_transpose2x2_cat(x1, self.up.weight, self.up.bias, self.up._packs, x2, cat))
         x1 = self.up(x1)
         x2 = ops.as_activation(x2, x1.dtype)
         return self.conv(ops.cat_pad(x2, x1))
@@ -284,13 +288,39 @@ def add_unet_branch(m, in_channels, base_c, levels=4):
         setattr(m, 'down%d' % (i + 1), Down(base_c << i, base_c << (i + 1)))
 
 
+def _skip_into_cat(block, x, up):
+    """Run the encoder stage `block` (DoubleConv or Down) on x and return (skip, cat): when possible the stage's last
+    BatchNorm+ReLU writes the skip tensor straight into the first channel window of the tensor that `up` will
+    concatenate it into (cat, else None), which removes the copy of the skip half of torch.cat (S/C:119-124)."""
+    down = isinstance(block, Down)
+    dc = block[1] if down else block
+    fused = (isinstance(dc, DoubleConv) and isinstance(up, Up) and not has_hooks(block, up, up.up, *dc)
+             and not (down and has_hooks(*block)) and x.is_cuda and x.dim() == 4)
+    if fused:
+        n, _, h, w = x.shape
+        if down:
+            h, w = h // 2, w // 2
+        c_skip, c_up = dc[3].out_channels, up.up.out_channels
+        # the level below halves (floor) and the transposed convolution doubles: sizes must be even to line up
+        fused = h % 2 == 0 and w % 2 == 0 and h > 0 and w > 0 and up.conv[0].in_channels == c_skip + c_up
+    if not fused:
+        return block(x), None
+    dtype = act_dtype(x)
+    cat = ops.empty_nhwc(n, c_skip + c_up, h, w, dtype, x.device)
+    win = ops.alias_window(cat, 0, c_skip)
+    skip = dc(block[0](x), out=win) if down else dc(x, out=win)
+    if skip.data_ptr() != win.data_ptr():          # the block could not honour the window
+        return skip, None
+    return skip, cat
+
+
 def unet_branch_forward(m, x):
-    x1 = m.in_conv(x)
-    x2 = m.down1(x1)
-    x3 = m.down2(x2)
-    x4 = m.down3(x3)
+    x1, c1 = _skip_into_cat(m.in_conv, x, m.up4)
+    x2, c2 = _skip_into_cat(m.down1, x1, m.up3)
+    x3, c3 = _skip_into_cat(m.down2, x2, m.up2)
+    x4, c4 = _skip_into_cat(m.down3, x3, m.up1)
     x5 = m.down4(x4)
-    u = m.up1(x5, x4)
-    u = m.up2(u, x3)
-    u = m.up3(u, x2)
-    return m.up4(u, x1)
+    u = m.up1(x5, x4, c4)
+    u = m.up2(u, x3, c3)
+    u = m.up3(u, x2, c2)
+    return m.up4(u, x1, c1)

@@ -129,7 +129,7 @@ class MaxPool2d(tnn.MaxPool2d):
             raise NotImplementedError("MaxPool2d: only kernel 2, stride 2 (the `Down` layer) is implemented")
 
     def forward(self, x):
-        return ops.maxpool2x2(ops.as_activation(x, act_dtype(x)))
+        return ops.maxpool2x2(ops.as_activation(x, act_dtype(x), allow_window=True))
 
 
 class Upsample(tnn.Upsample):
@@ -170,7 +170,7 @@ def has_hooks(*mods):
     return False
 
 
-def conv_bn_act(x, conv, bn, act=_lib.ACT_RELU, residual=None):
+def conv_bn_act(x, conv, bn, act=_lib.ACT_RELU, residual=None, out=None):
     """conv -> BatchNorm (training statistics taken from the conv kernel's epilogue) -> (+residual) -> act."""
     y, stats = conv.raw(x, want_stats=bn.training)
-    return ops.bn_act(y, bn, residual=residual, stats=stats, act=act)
+    return ops.bn_act(y, bn, residual=residual, stats=stats, act=act, out=out)

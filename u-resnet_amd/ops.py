@@ -96,13 +96,25 @@ class _ToNHWC(Function):
         return to_nchw_raw(g, ctx.in_dtype), None
 
 
-def as_activation(x, dtype):
-    """Model-boundary conversion: any 4-D input -> dense NHWC tensor of the compute dtype."""
+def as_activation(x, dtype, allow_window=False):
+    """Model-boundary conversion: any 4-D input -> dense NHWC tensor of the compute dtype.  With allow_window a
+    channel window of a wider NHWC tensor (alias_window) passes through for the kernels that take a pitch."""
     if x.dim() != 4:
         raise ValueError("expected a 4-D NCHW tensor, got shape %s" % (tuple(x.shape),))
     if x.dtype == dtype and x.is_cuda and _is_nhwc_dense(x):
         return x
+    if x.dtype == dtype and x.is_cuda and _channel_pitch(x):
+        return x if allow_window else _g(x)
     return _ToNHWC.apply(x, dtype)
+
+
+def alias_window(buf, c0, c):
+    """Tensor over channels [c0, c0 + c) of the dense NHWC tensor `buf`, sharing its storage but not registered as a
+    view of it (autograd never sees the aliasing; the kernels that fill the windows write through raw pointers)."""
+    n, ct, h, w = buf.shape
+    t = torch.empty(0, dtype=buf.dtype, device=buf.device)
+    t.set_(buf.untyped_storage(), buf.storage_offset() + c0, (n, c, h, w), (h * w * ct, 1, w * ct, ct))
+    return t
 
 
 def _channel_pitch(x):
@@ -403,7 +415,7 @@ class _ConvT2x2Cat(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packs, skip):
+    def forward(ctx, x, weight, bias, packs, skip, buf):
         _require_gpu(x)
         cin, cout, kh, kw = weight.shape
         n, _, h, w = x.shape
@@ -411,11 +423,13 @@ class _ConvT2x2Cat(Function):
         d = _desc(x.shape, cout, 2, 2, 2, 0, x.dtype, oh=2 * h, ow=2 * w)
         d.out_ld = cs + cout
         wp = packs.get(weight, d, _lib.PACK_CONVT_FWD)
-        out = empty_nhwc(n, cs + cout, 2 * h, 2 * w, x.dtype, x.device)
+        # buf = (tensor,): the concatenated tensor, whose window [0, cs) the producer of `skip` has already written
+        out = empty_nhwc(n, cs + cout, 2 * h, 2 * w, x.dtype, x.device) if buf is None else buf[0]
         with _Timed("igemm_fwd", _conv_flops(d, True), d):
             call("ur_convT2x2_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), out.data_ptr() + cs * out.element_size(),
                  C.byref(d), _stream())
-        _copy_channels(skip, 0, cs, out, 0)
+        if buf is None:
+            _copy_channels(skip, 0, cs, out, 0)
         ctx.save_for_backward(x, weight)
         ctx.d, ctx.packs, ctx.has_bias, ctx.cs = d, packs, bias is not None, cs
         return out
@@ -443,12 +457,13 @@ class _ConvT2x2Cat(Function):
             # a channel window of g, not a copy: the skip tensor has a second consumer, so autograd adds this to
             # the other gradient in one pass; a lone consumer densifies it through _g()
             dskip = g[:, :cs]
-        return dx, dw, db, None, dskip
+        return dx, dw, db, None, dskip, None
 
 
-def conv_transpose2x2_cat(x, weight, bias, packs, skip):
-    """cat([skip, conv_transpose2x2(x)], dim=1); skip must have exactly twice x's height and width."""
-    return _ConvT2x2Cat.apply(x, weight, bias, packs, skip)
+def conv_transpose2x2_cat(x, weight, bias, packs, skip, buf=None):
+    """cat([skip, conv_transpose2x2(x)], dim=1); skip must have exactly twice x's height and width.  With `buf` (the
+    dense concatenated tensor whose first window already holds `skip`, see alias_window) nothing is copied."""
+    return _ConvT2x2Cat.apply(x, weight, bias, packs, skip, None if buf is None else (buf,))
 
 
 class _GConv3x3(Function):
@@ -493,7 +508,7 @@ def gconv3x3(x, weight):
 # ------------------------------------------------------------------------------ batch norm (+act, +residual)
 class _BNAct(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, stats, running_mean, running_var, nbt, training, momentum, eps, act):
+    def forward(ctx, y, gamma, beta, residual, stats, running_mean, running_var, nbt, training, momentum, eps, act, out):
         _require_gpu(y)
         n, c, h, w = y.shape
         rows = n * h * w
@@ -510,11 +525,17 @@ class _BNAct(Function):
         else:
             call("ur_bn_eval_prepare", running_mean.data_ptr(), running_var.data_ptr(), c, eps, mean.data_ptr(),
                  invstd.data_ptr(), _stream())
-        z = torch.empty_like(y, memory_format=CL)
+        if out is None:
+            z, z_ld = torch.empty_like(y, memory_format=CL), c
+        else:                                        # (window,): a channel window of a wider tensor (alias_window)
+            z = out[0]
+            z_ld = _channel_pitch(z)
+            if tuple(z.shape) != tuple(y.shape) or z.dtype != y.dtype or not z_ld:
+                raise RuntimeError("bn_act: `out` must be a channel window with y's shape and dtype")
         tb = y.numel() * y.element_size()            # bytes of one pass over the tensor
         with _Timed("hbm:bn_fwd", tb * (3 if residual is not None else 2)):
             call("ur_bn_act_fwd", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                 _p(residual), act, z.data_ptr(), _dt(y), rows, c, _stream())
+                 _p(residual), act, z.data_ptr(), _dt(y), rows, c, z_ld, _stream())
         # the ReLU mask is recomputed from y in backward unless a residual was added before the activation
         ctx.save_for_backward(y, z if (act and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.act, ctx.eval, ctx.has_res = act, not training, residual is not None
@@ -544,11 +565,12 @@ class _BNAct(Function):
             call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
                  gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres),
                  _dt(y), rows, c, _stream())
-        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
-def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU):
-    """BatchNorm2d module `bn` applied to y, fused with an optional residual add and ReLU."""
+def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU, out=None):
+    """BatchNorm2d module `bn` applied to y, fused with an optional residual add and ReLU.  `out`: optional
+    channel window (alias_window) to write the result into."""
     training = bn.training or bn.running_mean is None
     if training and bn.momentum is None:
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not implemented")
@@ -557,7 +579,8 @@ def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU):
                         bn.running_mean if (track or not training) else None,
                         bn.running_var if (track or not training) else None,
                         bn.num_batches_tracked if track else None,
-                        training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, act)
+                        training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, act,
+                        None if out is None else (out,))
 
 
 # ------------------------------------------------------------------------------ spatial ops
@@ -568,7 +591,8 @@ class _MaxPool2x2(Function):
         n, c, h, w = x.shape
         y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
         idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
-        call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _stream())
+        call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _channel_pitch(x) or c,
+             _stream())
         ctx.save_for_backward(idx)
         ctx.shape = (n, c, h, w)
         return y
