@@ -26,22 +26,33 @@ def main():
             args = (C.c_void_p(dz.data_ptr()), C.c_void_p(y.data_ptr()), None, C.c_void_p(mean.data_ptr()),
                     C.c_void_p(invstd.data_ptr()), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), 1, 1,
                     C.c_longlong(rows), c, C.c_void_p(part.data_ptr()), st)
-            runs.append((os.path.basename(path), lib, args, part))
+            z = torch.empty_like(y)
+            fargs = (C.c_void_p(y.data_ptr()), C.c_void_p(mean.data_ptr()), C.c_void_p(invstd.data_ptr()),
+                     C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), None, 1, C.c_void_p(z.data_ptr()), 1,
+                     C.c_longlong(rows), c, 0, st)
+            sums = torch.rand(c, 2, device=dev)
+            aargs = (C.c_void_p(dz.data_ptr()), C.c_void_p(y.data_ptr()), None, C.c_void_p(mean.data_ptr()),
+                     C.c_void_p(invstd.data_ptr()), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
+                     C.c_void_p(sums.data_ptr()), 1, 0, C.c_void_p(z.data_ptr()), None, 1, C.c_longlong(rows), c, st)
+            runs.append((os.path.basename(path), lib, args, part, fargs, aargs, z, sums))
         best = {}
         for rep in range(3):
-            for name, lib, args, _ in runs:
-                for _ in range(5):
-                    assert lib.ur_bn_act_bwd_reduce(*args) == 0
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    lib.ur_bn_act_bwd_reduce(*args)
-                e1.record()
-                torch.cuda.synchronize()
-                best[name] = min(best.get(name, 1e9), e0.elapsed_time(e1) / 20)
-        for name, _, _, _ in runs:
-            ms = best[name]
-            print("rows %9d C %4d  %-14s %8.1f us  %6.2f TB/s" % (rows, c, name, ms * 1e3, 2.0 * rows * c * 2 / ms / 1e9), flush=True)
+            for r in runs:
+                name, lib = r[0], r[1]
+                for kind, fn, a, passes in (("reduce", lib.ur_bn_act_bwd_reduce, r[2], 2), ("fwd", lib.ur_bn_act_fwd, r[4], 2),
+                                            ("apply", lib.ur_bn_act_bwd_apply, r[5], 3)):
+                    for _ in range(5):
+                        assert fn(*a) == 0
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        fn(*a)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    key = (name, kind, passes)
+                    best[key] = min(best.get(key, 1e9), e0.elapsed_time(e1) / 20)
+        for (name, kind, passes), ms in best.items():
+            print("rows %9d C %4d  %-14s %-7s %8.1f us  %6.2f TB/s" % (rows, c, name, kind, ms * 1e3, passes * rows * c * 2 / ms / 1e9), flush=True)
 
 
 if __name__ == "__main__":

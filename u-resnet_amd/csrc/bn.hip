@@ -5,6 +5,9 @@
 // one partial row per workgroup (summed later in a fixed order: reproducible, no atomics).
 #include "ur_common.h"
 
+#ifndef UR_RED_GRID_CAP
+#define UR_RED_GRID_CAP 2048
+#endif
 #ifndef UR_BN_RED_UNROLL
 #define UR_BN_RED_UNROLL 1
 #endif
@@ -289,7 +292,13 @@ struct Chan8 {
 // bf16, 8 channels per thread (16-byte accesses).  The grid stride is a multiple of C for the power-of-two
 // channel counts of the network, so a thread keeps its 8 channels for the whole walk (FIXED): constants are
 // loaded once and UNROLL independent 16-byte loads are in flight per tensor before the first use.
-constexpr int EW_UNROLL = 4;
+#ifndef UR_EW_UNROLL
+#define UR_EW_UNROLL 4
+#endif
+#ifndef UR_EW_BLOCKS_PER_CU
+#define UR_EW_BLOCKS_PER_CU 4
+#endif
+constexpr int EW_UNROLL = UR_EW_UNROLL;
 
 template <bool FIXED, bool RES>
 __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __restrict__ y, const float* __restrict__ mean,
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
 int ew_grid(long long pieces, int C) {
     long long g = (pieces + (long long)NT * EW_UNROLL - 1) / ((long long)NT * EW_UNROLL);
     if (g < 1) g = 1;
-    if (g > 256 * 8) g = 256 * 8;
+    if (g > 256 * UR_EW_BLOCKS_PER_CU) g = 256 * UR_EW_BLOCKS_PER_CU;
     int a = C, b = NT * 8;
     while (b) { const int t = a % b; a = b; b = t; }
     const int q = C / a;
@@ -490,7 +499,7 @@ int reduce_grid(long long rows, int C, int vec) {
     int slots = NT / cqb;
     long long g = (rows + (long long)slots * 8 - 1) / ((long long)slots * 8);     // >= 8 rows per thread
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;
+    if (g > UR_RED_GRID_CAP) g = UR_RED_GRID_CAP;
     return (int)g;
 }
 
