@@ -459,3 +459,73 @@ def test_cifar_model_fp32_matches_reference(pkg):
             nograd = [k for k, p in m.named_parameters() if p.grad is None]
             assert nograd == list(rec["nograd_keys"])
     assert np.allclose(losses, rec["losses"], rtol=2e-3), (losses, rec["losses"])
+
+
+# ----------------------------------------------------------------------------- fused concatenation paths
+def test_channel_window_ops_are_bit_exact(pkg):
+    """BatchNorm+ReLU into a channel window, max-pool from a window, ConvTranspose into a window == the dense ops."""
+    ops = pkg.ops
+    torch.manual_seed(3)
+    for dtype in (torch.bfloat16, torch.float32):
+        n, c, h, w, cup = 2, 16, 12, 20, 24
+        y = ops.as_activation(torch.randn(n, c, h, w, device=DEV), dtype)
+        bn = pkg.nn.BatchNorm2d(c).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        dense = ops.bn_act(y, bn)
+        buf = ops.empty_nhwc(n, c + cup, h, w, dtype, DEV).fill_(7.0)
+        win = ops.alias_window(buf, 0, c)
+        got = ops.bn_act(y, bn, out=win)
+        assert got.data_ptr() == buf.data_ptr()
+        assert torch.equal(buf[:, :c], dense) and bool((buf[:, c:] == 7.0).all())
+        assert torch.equal(ops.maxpool2x2(win), ops.maxpool2x2(dense))
+        # transposed convolution + concatenation
+        x = ops.as_activation(torch.randn(n, 32, h // 2, w // 2, device=DEV), dtype).requires_grad_(True)
+        wt = (torch.randn(32, cup, 2, 2, device=DEV) * 0.1).requires_grad_(True)
+        b = torch.randn(cup, device=DEV).requires_grad_(True)
+        skip = dense.detach().clone().requires_grad_(True)
+        ref = ops.cat_pad(skip, ops.conv_transpose2x2(x, wt, b, ops.PackedWeights()))
+        g = ops.as_activation(torch.randn(n, c + cup, h, w, device=DEV), dtype)
+        ref_grads = torch.autograd.grad(ref, (x, wt, b, skip), g)
+        for use_buf in (False, True):
+            if use_buf:
+                out = ops.conv_transpose2x2_cat(x, wt, b, ops.PackedWeights(), win, buf)
+                assert out.data_ptr() == buf.data_ptr()
+            else:
+                out = ops.conv_transpose2x2_cat(x, wt, b, ops.PackedWeights(), skip)
+            assert torch.equal(out, ref)
+            inputs = (x, wt, b) if use_buf else (x, wt, b, skip)
+            for a, r in zip(torch.autograd.grad(out, inputs, g), ref_grads):
+                assert torch.equal(ops._g(a) if a.dim() == 4 else a, r)
+
+
+def test_seg_model_ragged_size_matches_oracle(pkg, oracle):
+    """36 x 52 input: level 3 is 9 x 13, so that Up block pads (unfused path) while the others write the skip tensor
+    and the transposed convolution straight into the concatenated tensor."""
+    torch.manual_seed(0)
+    m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 8).set_compute_dtype(torch.float32).to(DEV).train()
+    ref = oracle.UResNetNewEUCB(19, 3, 8).train()
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 36, 52, generator=g)
+    tgt = torch.randint(0, 19, (2, 36, 52), generator=g)
+    tgt[torch.rand(tgt.shape, generator=g) < 0.1] = 255
+    out = m(x.to(DEV))
+    loss = pkg.train.compute_loss(out, tgt.to(DEV))
+    loss.backward()
+    ro = ref(x)
+    rl = torch.nn.functional.cross_entropy(ro, tgt, ignore_index=255)
+    rl.backward()
+    assert rel_l2(host(pkg, out), ro.detach()) < 1e-4
+    assert abs(loss.item() - rl.item()) < 1e-5 * abs(rl.item())
+    errs = []
+    rp = dict(ref.named_parameters())
+    big = max(p.grad.norm().item() for p in rp.values() if p.grad is not None)
+    for k, p in m.named_parameters():
+        if rp[k].grad is None:
+            assert p.grad is None, k
+            continue
+        nrm = rp[k].grad.double().norm().item()
+        if nrm > 1e-5 * big:
+            errs.append(abs(p.grad.double().norm().item() - nrm) / nrm)
+    assert np.median(errs) < 1e-4 and max(errs) < 3e-2, (np.median(errs), max(errs))
