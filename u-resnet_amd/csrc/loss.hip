@@ -72,6 +72,72 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* __restrict__ logits
     }
 }
 
+// Dense logits (ld == classes) with short rows: a thread-per-pixel walk reads and writes 2-byte elements 38 bytes
+// apart, so the staged variants move each workgroup's 256 rows (one contiguous, 16-byte aligned span) through LDS
+// with 16-byte accesses and do the per-pixel arithmetic on the LDS copy.
+constexpr int CE_STAGE_BYTES = 32768;              // rows of at most 128 bytes
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(NT) void ce_staged_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                       long long rows, int classes, long long ignore_index,
+                                                       float* __restrict__ lse, float* __restrict__ partial,
+                                                       const float* __restrict__ count, const float* __restrict__ gout,
+                                                       T* __restrict__ dlogits) {
+    __shared__ uint4 stage[CE_STAGE_BYTES / 16];
+    T* tile = reinterpret_cast<T*>(stage);
+    const int row_bytes = classes * (int)sizeof(T);
+    const int span16 = NT * row_bytes / 16;        // 16-byte pieces of a full 256-row span (exact: 256 * anything)
+    float nll = 0.f, cnt = 0.f;
+    float scale = 0.f;
+    if (BWD) scale = (gout ? gout[0] : 1.f) / count[0];
+    const long long nblocks = (rows + NT - 1) / NT;
+    for (long long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const long long r0 = b * NT;
+        const int nrows = (int)((rows - r0) < NT ? (rows - r0) : NT);
+        const int pieces = nrows == NT ? span16 : (nrows * row_bytes + 15) / 16;
+        const uint4* src = reinterpret_cast<const uint4*>(logits + r0 * classes);
+        if (nrows == NT) {
+            for (int i = threadIdx.x; i < pieces; i += NT) stage[i] = src[i];
+        } else {                                    // last span: element-wise, it may end inside a 16-byte piece
+            for (int i = threadIdx.x; i < nrows * classes; i += NT) tile[i] = logits[r0 * classes + i];
+        }
+        __syncthreads();
+        const int rl = threadIdx.x;
+        if (rl < nrows) {
+            T* row = tile + rl * classes;
+            const long long t = target[r0 + rl];
+            const bool valid = t != ignore_index && t >= 0 && t < classes;
+            if (!BWD) {
+                float m = -INFINITY;
+                for (int c = 0; c < classes; ++c) m = fmaxf(m, ur_to_float(row[c]));
+                float sum = 0.f;
+                for (int c = 0; c < classes; ++c) sum += expf(ur_to_float(row[c]) - m);
+                const float l = m + logf(sum);
+                lse[r0 + rl] = l;
+                if (valid) { nll += l - ur_to_float(row[t]); cnt += 1.f; }
+            } else {
+                const float l = lse[r0 + rl];
+                for (int c = 0; c < classes; ++c) {
+                    float g = 0.f;
+                    if (valid) g = (expf(ur_to_float(row[c]) - l) - (c == t ? 1.f : 0.f)) * scale;
+                    row[c] = ur_from_float<T>(g);
+                }
+            }
+        }
+        if (BWD) {
+            __syncthreads();
+            uint4* dst = reinterpret_cast<uint4*>(dlogits + r0 * classes);
+            if (nrows == NT) {
+                for (int i = threadIdx.x; i < pieces; i += NT) dst[i] = stage[i];
+            } else {
+                for (int i = threadIdx.x; i < nrows * classes; i += NT) dlogits[r0 * classes + i] = tile[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (!BWD) block_sum2(nll, cnt, partial + (size_t)blockIdx.x * 2);
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void bce_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
                                                      long long count, float* __restrict__ partial) {
@@ -136,6 +202,12 @@ int ur_ce_fwd(const void* logits, int dtype, const int64_t* target, long long ro
     UR_REQUIRE(ws_bytes >= ur_loss_workspace(rows), "ce_fwd: workspace too small");
     const int grid = loss_blocks(rows);
     float* partial = (float*)workspace;
+    const int esz = dtype == UR_BF16 ? 2 : 4;
+    if (ld == classes && classes * esz <= CE_STAGE_BYTES / NT && ((uintptr_t)logits % 16) == 0) {
+        UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ce_staged_kernel<T, false>), dim3(grid), dim3(NT), 0, (hipStream_t)s,
+                                                    (const T*)logits, target, rows, classes, ignore_index, lse, partial,
+                                                    (const float*)nullptr, (const float*)nullptr, (T*)nullptr));
+    } else
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ce_fwd_kernel<T>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)logits,
                                                 target, rows, classes, ld, ignore_index, lse, partial));
     if (int e = ur_check_launch("ce_fwd")) return e;
@@ -148,6 +220,14 @@ int ur_ce_bwd(const void* logits, int dtype, const int64_t* target, long long ro
               ur_stream_t s) {
     UR_REQUIRE(logits && target && lse && count && dlogits && rows > 0 && classes > 0 && ld >= classes && dld >= classes,
                "ce_bwd: bad arguments");
+    const int esz = dtype == UR_BF16 ? 2 : 4;
+    if (ld == classes && dld == classes && classes * esz <= CE_STAGE_BYTES / NT && ((uintptr_t)logits % 16) == 0 &&
+        ((uintptr_t)dlogits % 16) == 0) {
+        UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ce_staged_kernel<T, true>), dim3(loss_blocks(rows)), dim3(NT), 0,
+                                                    (hipStream_t)s, (const T*)logits, target, rows, classes, ignore_index,
+                                                    const_cast<float*>(lse), (float*)nullptr, count, gout, (T*)dlogits));
+        return ur_check_launch("ce_bwd");
+    }
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(loss_blocks(rows)), dim3(NT), 0, (hipStream_t)s,
                                                 (const T*)logits, target, rows, classes, ld, ignore_index, lse, count, gout,
                                                 (T*)dlogits, dld));
