@@ -152,7 +152,8 @@ def test_conv_transpose2x2(pkg, shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("c,cpg,hw", [(32, 4, (16, 24)), (32, 1, (16, 24)), (512, 4, (12, 12)), (8, 1, (5, 7))])
+@pytest.mark.parametrize("c,cpg,hw", [(32, 4, (16, 24)), (32, 1, (16, 24)), (512, 4, (12, 12)), (8, 1, (5, 7)),
+                                      (64, 4, (37, 50)), (24, 4, (9, 9))])
 def test_grouped_conv3x3(pkg, c, cpg, hw, dtype):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, c, *hw, generator=g)

@@ -139,10 +139,98 @@ __global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__
     }
 }
 
+// bf16, 4 channels per group, on the matrix cores.  v_mfma_f32_4x4x4_16b_bf16 multiplies 16 independent
+// 4x4 blocks per wave: a block is (channel quad q, 4 consecutive pixels of a row).  Lane (block, j) supplies
+// the 8-byte quad it loaded for pixel j as the B column and receives the 4 output channels of pixel j, so
+// loads and stores keep the (pixel, quad) layout of the direct kernel; lane (block, i) supplies row i of the
+// tap's 4x4 weight block (bf16, 18 registers for all 9 taps).  Every lane walks down a column strip of RS
+// rows with a 3x3 register window: 3 loads per output instead of 9.
+//   grid.x = image * row strips * column strips, grid.y = quad blocks of QB = min(Q, 64) quads
+template <bool DGRAD>
+__global__ __launch_bounds__(NT) void gconv3x3_mfma_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
+                                                           bf16_t* __restrict__ out, int H, int W, int C, int QB, int RS,
+                                                           int xstrips, int ystrips) {
+    const int lane4 = threadIdx.x & 3;
+    const int gb = threadIdx.x >> 2;                         // 0..63: block index within the workgroup
+    const int q = blockIdx.y * QB + gb % QB;
+    const int pg = gb / QB;                                  // pixel group within the workgroup
+    const int PG = 64 / QB;
+    int bid = blockIdx.x;
+    const int xs = bid % xstrips; bid /= xstrips;
+    const int ys = bid % ystrips;
+    const int n = bid / ystrips;
+    const int x = (xs * PG + pg) * 4 + lane4;
+    const int y0 = ys * RS;
+    const int y1 = min(y0 + RS, H);
+
+    // weight rows: forward A[i][k] = w[q*4+i][k][tap]; backward-data A[i][k] = w[q*4+k][i][tap]
+    s16x4_t wt[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        bf16x4_t v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[k] = (bf16_t)(DGRAD ? w[((size_t)(q * 4 + k) * 4 + lane4) * 9 + tap] : w[((size_t)(q * 4 + lane4) * 4 + k) * 9 + tap]);
+        wt[tap] = __builtin_bit_cast(s16x4_t, v);
+    }
+
+    const bool xin = x < W;
+    const bool xl = xin && x >= 1, xr = x + 1 < W;
+    const bf16_t* img = in + (size_t)n * H * W * C + q * 4;
+    const s16x4_t zero = {0, 0, 0, 0};
+    auto load_row = [&](int yy, s16x4_t* row) {
+        const bool yok = (unsigned)yy < (unsigned)H;
+        const bf16_t* p = img + ((size_t)yy * W + x) * C;
+        row[0] = (yok && xl) ? *reinterpret_cast<const s16x4_t*>(p - C) : zero;
+        row[1] = (yok && xin) ? *reinterpret_cast<const s16x4_t*>(p) : zero;
+        row[2] = (yok && xr) ? *reinterpret_cast<const s16x4_t*>(p + C) : zero;
+    };
+    s16x4_t win[3][3];
+    load_row(y0 - 1, win[0]);
+    load_row(y0, win[1]);
+    for (int y = y0; y < y1; ++y) {
+        load_row(y + 1, win[2]);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wt[ky * 3 + kx], DGRAD ? win[2 - ky][2 - kx] : win[ky][kx], acc, 0, 0, 0);
+        if (xin) ur_store4(out + (((size_t)n * H + y) * W + x) * C + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { win[0][k] = win[1][k]; win[1][k] = win[2][k]; }
+    }
+}
+
+// geometry the matrix-core kernel covers: quads per workgroup divide 64, or 64 divides the quad count
+static bool mfma_gconv_ok(int c, int cpg) {
+    const int Q = c / 4;
+    return cpg == 4 && (Q >= 64 ? Q % 64 == 0 : 64 % Q == 0);
+}
+
+template <bool DGRAD>
+void launch_gconv_mfma(const bf16_t* in, const float* w, bf16_t* out, int n, int h, int w_, int c, hipStream_t st) {
+    const int Q = c / 4;
+    const int QB = Q < 64 ? Q : 64;
+    const int PG = 64 / QB;
+    const int xstrips = ur_cdiv(w_, 4 * PG);
+    int RS = 32;
+    while (RS > 4 && (long long)n * ur_cdiv(h, RS) * xstrips * (Q / QB) < 2048) RS >>= 1;
+    const int ystrips = ur_cdiv(h, RS);
+    hipLaunchKernelGGL((gconv3x3_mfma_kernel<DGRAD>), dim3((unsigned)(n * ystrips * xstrips), Q / QB), dim3(NT), 0, st, in, w, out,
+                       h, w_, c, QB, RS, xstrips, ystrips);
+}
+
 template <typename T, bool DGRAD>
 void launch_gconv(const T* in, const float* w, T* out, int n, int h, int w_, int c, int cpg, hipStream_t st) {
     const int Q = c / 4;
     const long long P = (long long)n * h * w_;
+    if constexpr (ElemTraits<T>::dtype == UR_BF16) {
+        if (mfma_gconv_ok(c, cpg) && (long long)n * ur_cdiv(h, 4) * ur_cdiv(w_, 4) < (1LL << 31)) {
+            launch_gconv_mfma<DGRAD>(in, w, out, n, h, w_, c, st);
+            return;
+        }
+    }
     if (NT % Q == 0) {
         const int PS = NT / Q;
         const int grid = ur_grid_1d(P, PS, 256 * 8);
@@ -245,23 +333,13 @@ __global__ __launch_bounds__(NT) void gconv3x3_wgrad_kernel(const T* __restrict_
     }
 }
 
-// dw[i] = sum_p partial[p][i]; 32 outputs x 8 partial lanes per workgroup, fixed summation order
+// dw[i] = sum_p partial[p][i], fixed summation order
+template <int SL>
 __global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, long long wsz,
                                                                  float* __restrict__ dw) {
-    __shared__ float red[8][32];
-    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const long long i = blockIdx.x * 32LL + ol;
-    float s = 0.f;
-    if (i < wsz)
-        for (int p = sl; p < nparts; p += 8) s += partial[(long long)p * wsz + i];
-    red[sl][ol] = s;
-    __syncthreads();
-    if (sl == 0 && i < wsz) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][ol];
-        dw[i] = t;
-    }
+    long long i;
+    float t;
+    if (ur_slab_sum<SL>(partial, wsz, nparts, i, t)) dw[i] = t;
 }
 
 int wgrad_blocks(long long P, int C) {
@@ -317,7 +395,10 @@ int ur_gconv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace,
     });
     if (int e = ur_check_launch("gconv3x3_wgrad")) return e;
     const long long wsz = (long long)c * cpg * 9;
-    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((unsigned)((wsz + 31) / 32)), dim3(256), 0, (hipStream_t)s, partial, grid, wsz, dw);
+    if (ur_slab_lanes(grid) == 32)
+        hipLaunchKernelGGL(gconv_wgrad_reduce_kernel<32>, dim3(ur_slab_grid(wsz, 32)), dim3(256), 0, (hipStream_t)s, partial, grid, wsz, dw);
+    else
+        hipLaunchKernelGGL(gconv_wgrad_reduce_kernel<8>, dim3(ur_slab_grid(wsz, 8)), dim3(256), 0, (hipStream_t)s, partial, grid, wsz, dw);
     return ur_check_launch("gconv3x3_wgrad_reduce");
 }
 

@@ -258,6 +258,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// the same sum with 16-byte slab reads, for slabs whose length is a multiple of 4
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ dw, int O, int I,
+                                                            int taps, int nsplit) {
+    long long idx;
+    float t;
+    if (!ur_slab_sum<SL>(ws, (long long)O * I * taps, nsplit, idx, t)) return;
+    const int o = (int)(idx / ((long long)I * taps));
+    const int rem = (int)(idx - (long long)o * I * taps);
+    const int tap = rem / I, i = rem - tap * I;
+    dw[((long long)o * I + i) * taps + tap] = t;
+}
+
 struct WgradPlan { int mtiles, ntiles, nsplit, stages_per_split; };
 
 template <typename T>
@@ -295,8 +308,15 @@ int launch_wgrad(WgradParams& p, float* dw, hipStream_t st) {
     else hipLaunchKernelGGL((conv_wgrad_kernel<T, 1, 1>), grid, dim3(NTHREADS), 0, st, p);
     if (int e = ur_check_launch("conv_wgrad")) return e;
     const long long per = (long long)p.O * p.Kred;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, p.ws, dw, p.O, p.I,
-                       p.kh * p.kw, pl.nsplit);
+    if (per % 4 != 0)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, p.ws, dw, p.O, p.I,
+                           p.kh * p.kw, pl.nsplit);
+    else if (ur_slab_lanes(pl.nsplit) == 32)
+        hipLaunchKernelGGL(wgrad_reduce4_kernel<32>, dim3(ur_slab_grid(per, 32)), dim3(256), 0, st, p.ws, dw, p.O, p.I,
+                           p.kh * p.kw, pl.nsplit);
+    else
+        hipLaunchKernelGGL(wgrad_reduce4_kernel<8>, dim3(ur_slab_grid(per, 8)), dim3(256), 0, st, p.ws, dw, p.O, p.I,
+                           p.kh * p.kw, pl.nsplit);
     return ur_check_launch("wgrad_reduce");
 }
 

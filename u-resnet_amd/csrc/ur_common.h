@@ -64,6 +64,46 @@ __device__ __forceinline__ float ur_wave_sum(float v) {
     return v;
 }
 
+// Sum of `nsplit` fp32 slabs of `per` values each (per % 4 == 0, slabs 16-byte aligned).  A 256-thread
+// workgroup covers 1024 / SL consecutive values with SL split lanes per value: 16-byte loads, four loads in
+// flight per lane, fixed summation order.  Returns true in the threads that end up holding a finished value
+// (`idx`, `total`); those are consecutive threads with consecutive `idx`.
+template <int SL>
+__device__ __forceinline__ bool ur_slab_sum(const float* __restrict__ ws, long long per, int nsplit, long long& idx,
+                                            float& total) {
+    constexpr int OL = 256 / SL;
+    __shared__ float4 red[SL][OL];
+    const int ol = threadIdx.x % OL, sl = threadIdx.x / OL;
+    const long long base = ((long long)blockIdx.x * OL + ol) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (base < per) {
+        const float* p = ws + base;
+        int k = sl;
+        for (; k + 3 * SL < nsplit; k += 4 * SL) {
+            const float4 a = ur_load4(p + (long long)k * per), b = ur_load4(p + (long long)(k + SL) * per);
+            const float4 c = ur_load4(p + (long long)(k + 2 * SL) * per), d = ur_load4(p + (long long)(k + 3 * SL) * per);
+            s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+            s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; k < nsplit; k += SL) {
+            const float4 a = ur_load4(p + (long long)k * per);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
+    red[sl][ol] = s;
+    __syncthreads();
+    if (threadIdx.x >= OL * 4) return false;
+    const float* r = reinterpret_cast<const float*>(&red[0][0]) + threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) t += r[k * OL * 4];
+    idx = (long long)blockIdx.x * OL * 4 + threadIdx.x;
+    total = t;
+    return idx < per;
+}
+static inline int ur_slab_lanes(int nsplit) { return nsplit >= 64 ? 32 : 8; }
+static inline unsigned ur_slab_grid(long long per, int lanes) { return (unsigned)((per + 1024 / lanes - 1) / (1024 / lanes)); }
+
 #define UR_DISPATCH_DTYPE(dtype, ...)                                  \
     do {                                                               \
         if ((dtype) == UR_F32) { typedef float T; __VA_ARGS__; }       \

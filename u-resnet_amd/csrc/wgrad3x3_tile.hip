@@ -159,27 +159,17 @@ __global__ __launch_bounds__(NTHREADS, MINW) void wgrad3x3_tile_kernel(WgTilePar
         }
 }
 
-// dw[co][ci][tap] = sum_s ws[s][co][tap][ci]; 32 outputs x 8 split lanes per workgroup
+// dw[co][ci][tap] = sum_s ws[s][co][tap][ci]
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout,
                                                               int Cin, int nsplit) {
-    __shared__ float red[8][32];
-    const long long per = (long long)Cout * 9 * Cin;
-    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const long long idx = blockIdx.x * 32LL + ol;
-    float s = 0.f;
-    if (idx < per)
-        for (int k = sl; k < nsplit; k += 8) s += ws[(long long)k * per + idx];
-    red[sl][ol] = s;
-    __syncthreads();
-    if (sl == 0 && idx < per) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][ol];
-        const int ci = (int)(idx % Cin);
-        const long long q = idx / Cin;
-        const int tap = (int)(q % 9), co = (int)(q / 9);
-        dw[((long long)co * Cin + ci) * 9 + tap] = t;
-    }
+    long long idx;
+    float t;
+    if (!ur_slab_sum<SL>(ws, (long long)Cout * 9 * Cin, nsplit, idx, t)) return;
+    const int ci = (int)(idx % Cin);
+    const long long q = idx / Cin;
+    const int tap = (int)(q % 9), co = (int)(q / 9);
+    dw[((long long)co * Cin + ci) * 9 + tap] = t;
 }
 
 struct Plan { int pairs, nsplit, tiles; };
@@ -239,8 +229,12 @@ int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, 
     else hipLaunchKernelGGL((wgrad3x3_tile_kernel<2, 2>), dim3(pl.pairs, pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
     if (int e = ur_check_launch("wgrad3x3_tile")) return e;
     const long long per = (long long)d->cout * 9 * d->cin;
-    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, (hipStream_t)s, p.ws, dw,
-                       d->cout, d->cin, pl.nsplit);
+    if (ur_slab_lanes(pl.nsplit) == 32)
+        hipLaunchKernelGGL(wgrad3x3_reduce_kernel<32>, dim3(ur_slab_grid(per, 32)), dim3(256), 0, (hipStream_t)s, p.ws, dw,
+                           d->cout, d->cin, pl.nsplit);
+    else
+        hipLaunchKernelGGL(wgrad3x3_reduce_kernel<8>, dim3(ur_slab_grid(per, 8)), dim3(256), 0, (hipStream_t)s, p.ws, dw,
+                           d->cout, d->cin, pl.nsplit);
     return ur_check_launch("wgrad3x3_reduce");
 }
 
