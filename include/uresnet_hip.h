@@ -144,9 +144,11 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
                   ur_stream_t s);
 /* backward pass 1: partial[nparts][c][2] = (sum g, sum g*xhat), g = dz masked by the ReLU (act != 0).
  * The mask comes from the saved output z when z != NULL, else it is recomputed from y (needs gamma, beta;
- * valid only when no residual was added before the activation). */
+ * valid only when no residual was added before the activation).  dz_ld = channel pitch of dz in elements
+ * (0 or c: dense); a larger pitch reads a channel window of a wider NHWC gradient (the backward of a
+ * torch.cat, S/C:119-124, S/C:280, without the split copy). */
 int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
-                         const float* gamma, const float* beta, int act, int dtype, long long rows, int c,
+                         const float* gamma, const float* beta, int act, int dtype, long long rows, int c, int dz_ld,
                          float* partial, ur_stream_t s);
 /* sums[c][2] = reduce(partial); dgamma = sums[.,1]; dbeta = sums[.,0]; `partial` is used as scratch */
 int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
@@ -155,7 +157,7 @@ int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dg
  * eval != 0 treats the statistics as constants: dy = gamma*invstd*g.  z may be NULL as in pass 1. */
 int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, const float* sums, int act, int eval, void* dy,
-                        void* dres, int dtype, long long rows, int c, ur_stream_t s);
+                        void* dres, int dtype, long long rows, int c, int dz_ld, ur_stream_t s);
 
 /* ---------------------------------------------------------------- spatial ops
  * MaxPool2d(2,2) (S/C:105), bilinear Upsample(scale, align_corners=False) (S/C:43,66,362;

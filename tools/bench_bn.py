@@ -25,7 +25,7 @@ def main():
             part = torch.empty(nrows, c, 2, device=dev)
             args = (C.c_void_p(dz.data_ptr()), C.c_void_p(y.data_ptr()), None, C.c_void_p(mean.data_ptr()),
                     C.c_void_p(invstd.data_ptr()), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), 1, 1,
-                    C.c_longlong(rows), c, C.c_void_p(part.data_ptr()), st)
+                    C.c_longlong(rows), c, 0, C.c_void_p(part.data_ptr()), st)
             z = torch.empty_like(y)
             fargs = (C.c_void_p(y.data_ptr()), C.c_void_p(mean.data_ptr()), C.c_void_p(invstd.data_ptr()),
                      C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), None, 1, C.c_void_p(z.data_ptr()), 1,
@@ -33,7 +33,7 @@ def main():
             sums = torch.rand(c, 2, device=dev)
             aargs = (C.c_void_p(dz.data_ptr()), C.c_void_p(y.data_ptr()), None, C.c_void_p(mean.data_ptr()),
                      C.c_void_p(invstd.data_ptr()), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
-                     C.c_void_p(sums.data_ptr()), 1, 0, C.c_void_p(z.data_ptr()), None, 1, C.c_longlong(rows), c, st)
+                     C.c_void_p(sums.data_ptr()), 1, 0, C.c_void_p(z.data_ptr()), None, 1, C.c_longlong(rows), c, 0, st)
             runs.append((os.path.basename(path), lib, args, part, fargs, aargs, z, sums))
         best = {}
         for rep in range(3):

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
                                                            const T* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int act, long long rows,
-                                                           int C, float* __restrict__ partial) {
+                                                           int C, int dz_ld, float* __restrict__ partial) {
     const bool have_z = act && z != nullptr;
     const bool recompute = act && z == nullptr;
     int cached_col = -1;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
             }
         }
         RowVec<T, VEC> g, yy, zz;
-        g.load(dz + r * C + col); yy.load(y + r * C + col);
+        g.load(dz + r * dz_ld + col); yy.load(y + r * C + col);
         if (have_z) zz.load(z + r * C + col);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -374,7 +374,8 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ sums,
                                                               int act, int eval, float inv_count,
-                                                              T* __restrict__ dy, T* __restrict__ dres, long long total, int C) {
+                                                              T* __restrict__ dy, T* __restrict__ dres, long long total, int C,
+                                                              int dz_ld) {
     const long long stride = (long long)gridDim.x * NT * VEC;
     const int cstep = (int)(stride % C);          // channel offset advances mod C: no 64-bit division in the loop
     int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * VEC) % C);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(const T* __restric
         const int c = cnext;
         cnext += cstep; if (cnext >= C) cnext -= C;
         RowVec<T, VEC> g, yy, zz;
-        g.load(dz + i); yy.load(y + i);
+        g.load(dz + (dz_ld == C ? i : (i / C) * dz_ld + c)); yy.load(y + i);
         const bool have_z = act && z != nullptr;
         if (have_z) zz.load(z + i);
         float o[VEC], gm[VEC];
@@ -415,10 +416,12 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
     const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y, const bf16_t* __restrict__ z, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ sums, int act, int eval, float inv_count, bf16_t* __restrict__ dy, bf16_t* __restrict__ dres,
-    long long total, int C) {
+    long long total, int C, int dz_ld) {
     const long long stride = (long long)gridDim.x * NT * 8;
     const int cstep = (int)(stride % C);          // channel offset advances mod C: no 64-bit division in the loop
+    const long long gstep = (stride / C) * dz_ld + cstep;         // dz may be a channel window: rows are dz_ld apart
     int cnext = (int)(((blockIdx.x * (long long)NT + threadIdx.x) * 8) % C);
+    long long goff = (((blockIdx.x * (long long)NT + threadIdx.x) * 8) / C) * dz_ld + cnext;
     Chan8 k;
     float s0[8], s1[8];
     auto load_consts = [&](int c) {
@@ -454,11 +457,11 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
     long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8;
     if (FIXED) {
         constexpr int U = HAVE_Z ? 2 : EW_UNROLL;
-        for (; i + (U - 1) * stride < total; i += U * stride) {
+        for (; i + (U - 1) * stride < total; i += U * stride, goff += U * gstep) {
             bf16x8_t g8[U], y8[U], z8[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                g8[u] = *reinterpret_cast<const bf16x8_t*>(dz + i + u * stride);
+                g8[u] = *reinterpret_cast<const bf16x8_t*>(dz + goff + u * gstep);
                 y8[u] = *reinterpret_cast<const bf16x8_t*>(y + i + u * stride);
                 if (HAVE_Z) z8[u] = *reinterpret_cast<const bf16x8_t*>(z + i + u * stride); else z8[u] = g8[u];
             }
@@ -467,11 +470,14 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
         }
     }
     for (; i < total; i += stride) {
+        const long long gi = goff;
+        goff += gstep;
         if (!FIXED) {
             load_consts(cnext);
-            cnext += cstep; if (cnext >= C) cnext -= C;
+            cnext += cstep;
+            if (cnext >= C) { cnext -= C; goff += dz_ld - C; }
         }
-        const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(dz + i);
+        const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(dz + gi);
         const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
         bf16x8_t z8 = g8;
         if (HAVE_Z) z8 = *reinterpret_cast<const bf16x8_t*>(z + i);
@@ -598,22 +604,25 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
 }
 
 int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
-                         const float* gamma, const float* beta, int act, int dtype, long long rows, int c, float* partial,
-                         ur_stream_t s) {
+                         const float* gamma, const float* beta, int act, int dtype, long long rows, int c, int dz_ld,
+                         float* partial, ur_stream_t s) {
     UR_REQUIRE(dz && y && mean && invstd && partial && rows > 0 && c > 0, "bn_act_bwd_reduce: bad arguments");
+    if (dz_ld == 0) dz_ld = c;
+    UR_REQUIRE(dz_ld >= c, "bn_act_bwd_reduce: gradient pitch %d is smaller than the channel count %d", dz_ld, c);
     UR_REQUIRE(!act || z || (gamma && beta), "bn_act_bwd_reduce: the activation mask needs z or (gamma, beta)");
-    const bool vec = (c % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(z);
+    const bool vec = (c % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(z) &&
+                     (dz_ld * (dtype == UR_BF16 ? 2 : 4)) % 16 == 0;
     const int grid = reduce_grid(rows, c, c % 4 == 0 ? 4 : 1);
     if (UR_BN_RED_VEC8 && dtype == UR_BF16 && vec && c % 8 == 0) {
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 8>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)dz,
-                           (const bf16_t*)y, (const bf16_t*)z, mean, invstd, gamma, beta, act, rows, c, partial);
+                           (const bf16_t*)y, (const bf16_t*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial);
         return ur_check_launch("bn_act_bwd_reduce");
     }
     UR_DISPATCH_DTYPE(dtype, {
         if (vec) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
-                                    (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, partial);
+                                    (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
-                                (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, partial);
+                                (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial);
     });
     return ur_check_launch("bn_act_bwd_reduce");
 }
@@ -630,13 +639,16 @@ int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dg
 
 int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, const float* sums, int act, int eval, void* dy, void* dres,
-                        int dtype, long long rows, int c, ur_stream_t s) {
+                        int dtype, long long rows, int c, int dz_ld, ur_stream_t s) {
     UR_REQUIRE(dz && y && mean && invstd && gamma && dy && rows > 0 && c > 0, "bn_act_bwd_apply: bad arguments");
+    if (dz_ld == 0) dz_ld = c;
+    UR_REQUIRE(dz_ld >= c, "bn_act_bwd_apply: gradient pitch %d is smaller than the channel count %d", dz_ld, c);
     UR_REQUIRE(!act || z || beta, "bn_act_bwd_apply: the activation mask needs z or beta");
     UR_REQUIRE(eval || sums, "bn_act_bwd_apply: training mode needs the reduced sums");
     const long long total = rows * c;
     const float inv_count = 1.f / (float)rows;
-    const bool al = aligned16(dz) && aligned16(y) && aligned16(z) && aligned16(dy) && aligned16(dres);
+    const bool al = aligned16(dz) && aligned16(y) && aligned16(z) && aligned16(dy) && aligned16(dres) &&
+                    (dz_ld * (dtype == UR_BF16 ? 2 : 4)) % 16 == 0;
     if (dtype == UR_BF16 && c % 8 == 0 && al && beta && aligned16(mean) && aligned16(invstd) && aligned16(gamma) &&
         aligned16(beta) && aligned16(sums)) {
         const int grid = ew_grid(total / 8, c);
@@ -645,7 +657,7 @@ int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const floa
 #define UR_BN_BWD(FIXED, HZ, DR)                                                                                          \
     hipLaunchKernelGGL((bn_act_bwd_apply_bf16x8_kernel<FIXED, HZ, DR>), dim3(grid), dim3(NT), 0, (hipStream_t)s,           \
                        (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, mean, invstd, gamma, beta, sums, act, eval,  \
-                       inv_count, (bf16_t*)dy, (bf16_t*)dres, total, c)
+                       inv_count, (bf16_t*)dy, (bf16_t*)dres, total, c, dz_ld)
         if (fixed) {
             if (have_z) { if (dres) UR_BN_BWD(true, true, true); else UR_BN_BWD(true, true, false); }
             else { if (dres) UR_BN_BWD(true, false, true); else UR_BN_BWD(true, false, false); }
@@ -660,10 +672,10 @@ int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const floa
     UR_DISPATCH_DTYPE(dtype, {
         if (vec) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 4>), dim3(ur_grid_1d(total / 4, NT)), dim3(NT), 0,
                                     (hipStream_t)s, (const T*)dz, (const T*)y, (const T*)z, mean, invstd, gamma, beta, sums,
-                                    act, eval, inv_count, (T*)dy, (T*)dres, total, c);
+                                    act, eval, inv_count, (T*)dy, (T*)dres, total, c, dz_ld);
         else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 1>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0, (hipStream_t)s,
                                 (const T*)dz, (const T*)y, (const T*)z, mean, invstd, gamma, beta, sums, act, eval,
-                                inv_count, (T*)dy, (T*)dres, total, c);
+                                inv_count, (T*)dy, (T*)dres, total, c, dz_ld);
     });
     return ur_check_launch("bn_act_bwd_apply");
 }

@@ -43,11 +43,20 @@ __global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* __restrict__ logits
 }
 
 // out[0] = sum, out[1] = count, out[2] = sum / count (mean; NaN when count == 0, like PyTorch)
-__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ out,
-                                     double fixed_count) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                                            float* __restrict__ out, double fixed_count) {
+    // one workgroup; lane t sums partials t, t+256, ... in double, then a fixed-order tree over the lanes
+    __shared__ double ss[256], cs[256];
     double s = 0.0, c = 0.0;
-    for (int i = 0; i < nparts; ++i) { s += partial[i * 2]; c += partial[i * 2 + 1]; }
+    for (int i = threadIdx.x; i < nparts; i += 256) { s += partial[i * 2]; c += partial[i * 2 + 1]; }
+    ss[threadIdx.x] = s; cs[threadIdx.x] = c;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) { ss[threadIdx.x] += ss[threadIdx.x + h]; cs[threadIdx.x] += cs[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    s = ss[0]; c = cs[0];
     if (fixed_count > 0.0) c = fixed_count;
     out[0] = (float)s; out[1] = (float)c; out[2] = (float)(s / c);
 }
@@ -211,7 +220,7 @@ int ur_ce_fwd(const void* logits, int dtype, const int64_t* target, long long ro
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ce_fwd_kernel<T>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)logits,
                                                 target, rows, classes, ld, ignore_index, lse, partial));
     if (int e = ur_check_launch("ce_fwd")) return e;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, grid, out3, 0.0);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, partial, grid, out3, 0.0);
     return ur_check_launch("ce_finalize");
 }
 
@@ -243,7 +252,7 @@ int ur_bce_fwd(const void* logits, int dtype, const float* target, long long cou
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bce_fwd_kernel<T>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)logits,
                                                 target, count, partial));
     if (int e = ur_check_launch("bce_fwd")) return e;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, grid, out3, (double)count);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, partial, grid, out3, (double)count);
     return ur_check_launch("bce_finalize");
 }
 

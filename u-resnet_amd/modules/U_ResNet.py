@@ -10,7 +10,7 @@ uresnet_amd.get_default_dtype()).
 from .. import nn as hnn
 from .. import ops
 from ._blocks import (BasicBlock, Bottleneck, DoubleConv, Down, EUCB, EUCB2, OutConv, ResTrunk, Up,  # noqa: F401
-                      act_layer, add_unet_branch, channel_shuffle, stem, unet_branch_forward)
+                      act_layer, add_unet_branch, channel_shuffle, has_hooks, stem, unet_branch_forward)
 
 __all__ = ["channel_shuffle", "act_layer", "EUCB", "EUCB2", "DoubleConv", "Down", "Up", "OutConv", "BasicBlock",
            "Bottleneck", "UNet", "UResNet", "UResNetNewEUCB", "UResNetNoEUCB", "UResNetNoResBlock"]
@@ -39,7 +39,21 @@ class _TwoBranch(ResTrunk):
 
     def forward(self, x):
         x = ops.as_activation(x, self.compute_dtype)
-        res_out = self.Upsample(self._res_forward(x))
+        res = self._res_forward(x)
+        n, _, h, w = x.shape
+        c_u, c_res = self.up4.conv[3].out_channels, self.out_conv[0].num_features - self.up4.conv[3].out_channels
+        if (isinstance(self.Upsample, (EUCB, EUCB2)) and not has_hooks(self.Upsample, self.up4, self.up4.conv)
+                and res.shape[2] * 2 == h and res.shape[3] * 2 == w and self.Upsample.out_channels == c_res):
+            # Feature Merge without copies: both branches write their result into its channel window of the merged
+            # tensor (S/C:280 torch.cat([u_out, res_out], dim=1))
+            cat = ops.empty_nhwc(n, c_u + c_res, h, w, x.dtype, x.device)
+            wu, wr = ops.alias_window(cat, 0, c_u), ops.alias_window(cat, c_u, c_res)
+            res_out = self.Upsample(res, out=wr)
+            u_out = unet_branch_forward(self, x, out=wu)
+            if u_out.data_ptr() == wu.data_ptr() and res_out.data_ptr() == wr.data_ptr():
+                return self.out_conv(ops.cat_windows(u_out, res_out, cat))
+            return self.out_conv(ops.cat_pad(ops.dense(u_out), ops.dense(res_out)))
+        res_out = self.Upsample(res)
         u_out = unet_branch_forward(self, x)
         return self.out_conv(ops.cat_pad(u_out, res_out))
 

@@ -60,13 +60,17 @@ class EUCB(hnn.Module):
             act_layer(activation, inplace=True))
         self.pwc = hnn.Sequential(hnn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0, bias=True))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: optional channel window for the result (honoured when no hooks are registered)."""
         x = ops.as_activation(x, act_dtype(x))
-        if has_hooks(self.up_dwc, *self.up_dwc, self.pwc, *self.pwc):
+        hooked = has_hooks(self.up_dwc, *self.up_dwc, self.pwc, *self.pwc)
+        if hooked:
             x = self.up_dwc(x)
         else:
             x = _cba(self.up_dwc, self.up_dwc[0](x), 1)
         x = channel_shuffle(x, self.in_channels)
+        if out is not None and not hooked:
+            return self.pwc[0].raw(x, out=out)[0]
         return self.pwc(x)
 
 
@@ -93,7 +97,8 @@ class EUCB2(hnn.Module):
     def _seqs(self):
         return [self.up_dwc1, self.up_dwc2] + ([self.up_dwc3] if self.stages == 3 else [])
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: optional channel window for the result (honoured when no hooks are registered)."""
         x = ops.as_activation(x, act_dtype(x))
         hooked = has_hooks(self.pwc, *self.pwc, *[m for s in self._seqs() for m in (s, *s)])
         for k, seq in enumerate(self._seqs()):
@@ -105,6 +110,8 @@ class EUCB2(hnn.Module):
                 x = _cba(seq, seq[0](x), 1)
             else:
                 x = _cba(seq, x, 0)
+        if out is not None and not hooked:
+            return self.pwc[0].raw(x, out=out)[0]
         return self.pwc(x)
 
 
@@ -148,18 +155,18 @@ class Up(hnn.Module):
         self.up = hnn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
         self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2, cat=None):
+    def forward(self, x1, x2, cat=None, out=None):
         """cat: the pre-allocated concatenated tensor whose first channel window already holds x2 (x2 is then
-        an alias of that window, see unet_branch_forward)."""
+        an alias of that window, see unet_branch_forward).  out: optional channel window for the result."""
         if not has_hooks(self.up) and x2.shape[2] == 2 * x1.shape[2] and x2.shape[3] == 2 * x1.shape[3]:
             # the transposed convolution writes straight into its half of the concatenated tensor
             x1 = ops.as_activation(x1, act_dtype(x1))
             if cat is None:
                 x2 = ops.as_activation(x2, x1.dtype)
-            return self.conv(ops.conv_transpose2x2_cat(x1, self.up.weight, self.up.bias, self.up._packs, x2, cat))
+            return self.conv(ops.conv_transpose2x2_cat(x1, self.up.weight, self.up.bias, self.up._packs, x2, cat), out=out)
         x1 = self.up(x1)
         x2 = ops.as_activation(x2, x1.dtype)
-        return self.conv(ops.cat_pad(x2, x1))
+        return self.conv(ops.cat_pad(x2, x1), out=out)
 
 
 class OutConv(hnn.Sequential):
@@ -314,7 +321,8 @@ def _skip_into_cat(block, x, up):
     return skip, cat
 
 
-def unet_branch_forward(m, x):
+def unet_branch_forward(m, x, out=None):
+    """out: optional channel window for the branch's result (see Up.forward)."""
     x1, c1 = _skip_into_cat(m.in_conv, x, m.up4)
     x2, c2 = _skip_into_cat(m.down1, x1, m.up3)
     x3, c3 = _skip_into_cat(m.down2, x2, m.up2)
@@ -323,4 +331,4 @@ def unet_branch_forward(m, x):
     u = m.up1(x5, x4, c4)
     u = m.up2(u, x3, c3)
     u = m.up3(u, x2, c2)
-    return m.up4(u, x1, c1)
+    return m.up4(u, x1, c1, out=out)

@@ -104,7 +104,7 @@ def as_activation(x, dtype, allow_window=False):
     if x.dtype == dtype and x.is_cuda and _is_nhwc_dense(x):
         return x
     if x.dtype == dtype and x.is_cuda and _channel_pitch(x):
-        return x if allow_window else _g(x)
+        return x if allow_window else _Dense.apply(x)
     return _ToNHWC.apply(x, dtype)
 
 
@@ -139,6 +139,23 @@ def _g(g):
         call("ur_copy_channels", g.data_ptr(), ld, 0, h, w, y.data_ptr(), c, 0, h, w, 0, 0, n, c, _dt(g), _stream())
         return y
     return to_nhwc_raw(g.contiguous(), g.dtype)
+
+
+class _Dense(Function):
+    """Channel window of a wider NHWC tensor -> dense NHWC copy."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _g(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def dense(x):
+    """x itself when it is a dense NHWC tensor, else a dense copy of the channel window."""
+    return x if _is_nhwc_dense(x) else _Dense.apply(x)
 
 
 class _ToNCHW(Function):
@@ -278,7 +295,7 @@ def _crop_channels(x, c):
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packs, stride, pad, want_stats):
+    def forward(ctx, x, weight, bias, packs, stride, pad, want_stats, out):
         _require_gpu(x)
         cout, cin, kh, kw = weight.shape
         if x.shape[1] != cin:
@@ -286,9 +303,15 @@ class _Conv2d(Function):
         d = _desc(x.shape, cout, kh, kw, stride, pad, x.dtype)
         if d.oh <= 0 or d.ow <= 0:
             raise RuntimeError("conv2d: kernel %dx%d does not fit input %dx%d" % (kh, kw, d.h, d.w))
-        y = empty_nhwc(d.n, cout, d.oh, d.ow, x.dtype, x.device)
+        tile = bias is None and use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 0)
+        win_ld = 0
+        if out is not None:                          # (window,): a channel window of a wider tensor (alias_window)
+            win_ld = _channel_pitch(out[0])
+            if tuple(out[0].shape) != (d.n, cout, d.oh, d.ow) or out[0].dtype != x.dtype or not win_ld:
+                raise RuntimeError("conv2d: `out` must be a channel window with the output's shape and dtype")
+        y = out[0] if (win_ld and not tile) else empty_nhwc(d.n, cout, d.oh, d.ow, x.dtype, x.device)
         stats = None
-        if bias is None and use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 0):
+        if tile:
             wp = packs.get_tile(weight, d, False)
             if want_stats:
                 rows = query("ur_conv3x3_tile_stats_rows", C.byref(d))
@@ -303,8 +326,13 @@ class _Conv2d(Function):
             if want_stats:
                 rows = query("ur_conv2d_stats_rows", C.byref(d))
                 stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
+            if win_ld:
+                d.out_ld = win_ld
             with _Timed("igemm_fwd", _conv_flops(d), d):
                 call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
+        if win_ld and tile:                          # the tile kernel writes dense tensors only
+            _copy_channels(y, 0, cout, out[0], 0)
+            y = out[0]
         ctx.save_for_backward(x, weight)          # x: as the kernel saw it (channel-padded on the generic path)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
         ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
@@ -316,16 +344,24 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, dy, _dstats):
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         d = ctx.d
         cout, cin = weight.shape[0], weight.shape[1]
-        dy = _g(dy)
+        d.out_ld = cout
         dx = dw = db = None
         tile_d = use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 1)
         tile_w = use_tile_kernel and query("ur_wgrad3x3_tile_supported", C.byref(d))
+        # the generic kernels read a channel window of a wider gradient in place (the backward of a torch.cat)
+        dy_ld = 0
+        if not (tile_d or tile_w) and cout % 8 == 0 and dy.is_cuda and dy.dtype == x.dtype and not _is_nhwc_dense(dy):
+            dy_ld = _channel_pitch(dy)
+        if dy_ld:
+            d.out_ld = dy_ld
+        else:
+            dy = _g(dy)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, cout, cout, x.device)
+            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, cout, d.out_ld, x.device)
         if cout % 8 and not (tile_d and tile_w):
             dy = _pad_channels(dy, _pad8(cout))
             d = _desc(x.shape, _pad8(cout), d.kh, d.kw, d.stride, d.pad, x.dtype)
@@ -355,11 +391,12 @@ class _Conv2d(Function):
                          C.byref(d), _stream())
             if (d.cout, d.cin) != (cout, cin):
                 dw = dw[:cout, :cin].contiguous()
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, packs, stride=1, pad=0, want_stats=False):
-    return _Conv2d.apply(x, weight, bias, packs, stride, pad, want_stats)
+def conv2d(x, weight, bias, packs, stride=1, pad=0, want_stats=False, out=None):
+    """`out`: optional channel window (alias_window) that receives the result."""
+    return _Conv2d.apply(x, weight, bias, packs, stride, pad, want_stats, None if out is None else (out,))
 
 
 class _ConvT2x2(Function):
@@ -547,13 +584,16 @@ class _BNAct(Function):
         n, c, h, w = y.shape
         rows = n * h * w
         dev = y.device
-        dz = _g(dz)
+        # a channel window of a wider gradient (the backward of a torch.cat) is read in place
+        dz_ld = _channel_pitch(dz) if (dz.is_cuda and dz.dtype == y.dtype) else 0
+        if not dz_ld:
+            dz, dz_ld = _g(dz), c
         nparts = query("ur_bn_stats_rows", rows, c)
         partial = torch.empty((nparts, c, 2), dtype=torch.float32, device=dev)
         tb = y.numel() * y.element_size()
         with _Timed("hbm:bn_bwd_reduce", tb * (3 if z is not None else 2)):
             call("ur_bn_act_bwd_reduce", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
-                 gamma.data_ptr(), beta.data_ptr(), ctx.act, _dt(y), rows, c, partial.data_ptr(), _stream())
+                 gamma.data_ptr(), beta.data_ptr(), ctx.act, _dt(y), rows, c, dz_ld, partial.data_ptr(), _stream())
         sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
@@ -564,7 +604,7 @@ class _BNAct(Function):
         with _Timed("hbm:bn_bwd_apply", tb * (3 + (z is not None) + (dres is not None))):
             call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
                  gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres),
-                 _dt(y), rows, c, _stream())
+                 _dt(y), rows, c, dz_ld, _stream())
         return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
@@ -698,6 +738,33 @@ class _CatPad(Function):
 
 def cat_pad(a, b):
     return _CatPad.apply(a, b)
+
+
+class _CatWindows(Function):
+    """torch.cat([a, b], dim=1) where a and b already ARE the two channel windows of `buf` (their producers wrote
+    them in place, see alias_window): nothing is copied in either direction, the gradients are channel windows of
+    the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ctx.ca = a.shape[1]
+        return buf[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _g(g)
+        return (g[:, :ctx.ca] if ctx.needs_input_grad[0] else None,
+                g[:, ctx.ca:] if ctx.needs_input_grad[1] else None, None)
+
+
+def cat_windows(a, b, buf):
+    """cat([a, b], dim=1) for a = alias_window(buf, 0, ca), b = alias_window(buf, ca, cb), both already written."""
+    ca, cb = a.shape[1], b.shape[1]
+    es = buf.element_size()
+    if (buf.shape[1] != ca + cb or a.data_ptr() != buf.data_ptr() or b.data_ptr() != buf.data_ptr() + ca * es
+            or _channel_pitch(a) != ca + cb or _channel_pitch(b) != ca + cb):
+        raise RuntimeError("cat_windows: a and b must be the two channel windows of buf")
+    return _CatWindows.apply(a, b, (buf,))
 
 
 class _ChannelShuffle(Function):
