@@ -106,7 +106,8 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, lon
 // g = dz masked by the ReLU: from the saved output z when given, else recomputed from y
 // ((y-mean)*invstd*gamma + beta > 0 has the sign of the stored activation).  A thread keeps one channel
 // group for its whole row walk, so the per-channel constants live in registers.
-template <typename T, int VEC>
+// PITCHED: dz is a channel window with its own row pitch (a second address chain; the dense case shares y's)
+template <typename T, int VEC, bool PITCHED>
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                            const T* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
             }
         }
         RowVec<T, VEC> g, yy, zz;
-        g.load(dz + r * dz_ld + col); yy.load(y + r * C + col);
+        g.load(dz + r * (PITCHED ? dz_ld : C) + col); yy.load(y + r * C + col);
         if (have_z) zz.load(z + r * C + col);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -485,6 +486,76 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
     }
 }
 
+// Backward reduction for bf16 with 8 channels per thread: thread (row slot, channel group) keeps its constants in
+// registers and has U rows (16-byte loads of dz, y and optionally z) in flight before the first use.
+// Requires C % 8 == 0 and NT % (C / 8) == 0.
+#ifndef UR_BN_RED8_UNROLL
+#define UR_BN_RED8_UNROLL 2
+#endif
+template <bool HAVE_Z, bool PITCHED>
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_bf16x8_kernel(
+    const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y, const bf16_t* __restrict__ z, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, int act, long long rows,
+    int C, int dz_ld, float* __restrict__ partial) {
+    constexpr int U = HAVE_Z ? 2 : UR_BN_RED8_UNROLL;
+    __shared__ float red[NT * 16];
+    const int cq = C >> 3, slots = NT / cq;
+    const int tid = threadIdx.x, slot = tid / cq, cg = tid - slot * cq, col = cg * 8;
+    Chan8 k;
+    k.load(mean, invstd, gamma, beta, col);
+    if (!act || HAVE_Z) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { k.ga[v] = 0.f; k.be[v] = 1.f; }          // mask always open (or taken from z)
+    }
+    float s0[8], s1[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    auto one = [&](const bf16x8_t& g8, const bf16x8_t& y8, const bf16x8_t& z8) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const float xh = ((float)y8[v] - k.m[v]) * k.is[v];
+            float pre = xh * k.ga[v] + k.be[v];
+            if (HAVE_Z) pre = (float)z8[v];
+            const float gv = pre > 0.f ? (float)g8[v] : 0.f;
+            s0[v] += gv; s1[v] += gv * xh;
+        }
+    };
+    const long long step = (long long)gridDim.x * slots;
+    long long r = (long long)blockIdx.x * slots + slot;
+    const bf16_t* py = y + r * C + col;
+    const bf16_t* pz = z + r * C + col;
+    const bf16_t* pg = dz + r * (PITCHED ? dz_ld : C) + col;
+    const long long ystep = step * C, gstep = step * (PITCHED ? dz_ld : C);
+    for (; r + (U - 1) * step < rows; r += U * step, py += U * ystep, pz += U * ystep, pg += U * gstep) {
+        bf16x8_t g8[U], y8[U], z8[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            g8[u] = *reinterpret_cast<const bf16x8_t*>(pg + u * gstep);
+            y8[u] = *reinterpret_cast<const bf16x8_t*>(py + u * ystep);
+            if (HAVE_Z) z8[u] = *reinterpret_cast<const bf16x8_t*>(pz + u * ystep); else z8[u] = g8[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(g8[u], y8[u], z8[u]);
+    }
+    for (; r < rows; r += step, py += ystep, pz += ystep, pg += gstep) {
+        const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(pg);
+        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(py);
+        bf16x8_t z8 = g8;
+        if (HAVE_Z) z8 = *reinterpret_cast<const bf16x8_t*>(pz);
+        one(g8, y8, z8);
+    }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { red[(v * 2) * NT + tid] = s0[v]; red[(v * 2 + 1) * NT + tid] = s1[v]; }
+    __syncthreads();
+    // output o = (value index i, channel group): fixed-order sum over the row slots
+    for (int o = tid; o < cq * 16; o += NT) {
+        const int i = o / cq, g = o - i * cq;
+        float t = 0.f;
+        for (int sl = 0; sl < slots; ++sl) t += red[i * NT + sl * cq + g];
+        partial[((size_t)blockIdx.x * C + g * 8 + (i >> 1)) * 2 + (i & 1)] = t;
+    }
+}
+
 // Elementwise grid: enough workgroups to fill the chip several times over, each thread walking EW_UNROLL+ pieces.
 // The count is rounded down to a multiple of C / gcd(C, NT * 8) when possible, which makes the grid stride a
 // multiple of C (a thread then keeps its channels for the whole walk) for channel counts such as 80 too.
@@ -613,17 +684,35 @@ int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const flo
     const bool vec = (c % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(z) &&
                      (dz_ld * (dtype == UR_BF16 ? 2 : 4)) % 16 == 0;
     const int grid = reduce_grid(rows, c, c % 4 == 0 ? 4 : 1);
+#define UR_BN_RED(TT, V)                                                                                             \
+    do {                                                                                                             \
+        if (dz_ld == c) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, V, false>), dim3(grid), dim3(NT), 0, (hipStream_t)s, \
+                                           (const TT*)dz, (const TT*)y, (const TT*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial); \
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, V, true>), dim3(grid), dim3(NT), 0, (hipStream_t)s,            \
+                                (const TT*)dz, (const TT*)y, (const TT*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial); \
+    } while (0)
+    if (dtype == UR_BF16 && vec && c % 8 == 0 && NT % (c / 8) == 0 && (dz_ld * 2) % 16 == 0 && aligned16(mean) &&
+        aligned16(invstd) && (!act || z || (aligned16(gamma) && aligned16(beta)))) {
+        const bool have_z = act && z;
+        const float* ga = gamma ? gamma : mean;        // constants are loaded unconditionally, then overridden
+        const float* be = beta ? beta : mean;
+#define UR_BN_RED8(HZ, PI)                                                                                            \
+    hipLaunchKernelGGL((bn_bwd_reduce_bf16x8_kernel<HZ, PI>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)dz, \
+                       (const bf16_t*)y, (const bf16_t*)z, mean, invstd, ga, be, act, rows, c, dz_ld, partial)
+        if (have_z) { if (dz_ld == c) UR_BN_RED8(true, false); else UR_BN_RED8(true, true); }
+        else { if (dz_ld == c) UR_BN_RED8(false, false); else UR_BN_RED8(false, true); }
+#undef UR_BN_RED8
+        return ur_check_launch("bn_act_bwd_reduce");
+    }
     if (UR_BN_RED_VEC8 && dtype == UR_BF16 && vec && c % 8 == 0) {
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 8>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)dz,
-                           (const bf16_t*)y, (const bf16_t*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial);
+        UR_BN_RED(bf16_t, 8);
         return ur_check_launch("bn_act_bwd_reduce");
     }
     UR_DISPATCH_DTYPE(dtype, {
-        if (vec) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
-                                    (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)dz,
-                                (const T*)y, (const T*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial);
+        if (vec) UR_BN_RED(T, 4);
+        else UR_BN_RED(T, 1);
     });
+#undef UR_BN_RED
     return ur_check_launch("bn_act_bwd_reduce");
 }
 
