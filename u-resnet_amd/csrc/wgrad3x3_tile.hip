@@ -28,7 +28,23 @@ struct WgTileParams {
     int N, H, W, Cin, Cout, ld_x, ld_dy;
     int tiles_x, tiles_y, tiles;
     int ci_blocks;
+    int pairs, nsplit, xcd_order;
 };
+
+// Workgroup id -> (channel-block pair, split).  Ids congruent mod 8 run on the same XCD (one L2 each): with
+// xcd_order every pair of a split lands on one XCD, so the x and dy tiles that the pairs of a split share are
+// fetched from memory once instead of once per XCD.
+__device__ __forceinline__ void wg_decode(const WgTileParams& p, int& pair, int& split) {
+    const int id = blockIdx.x;
+    if (p.xcd_order) {
+        const int xcd = id & 7, j = id >> 3;
+        pair = j % p.pairs;
+        split = (j / p.pairs) * 8 + xcd;
+    } else {
+        pair = id % p.pairs;
+        split = id / p.pairs;
+    }
+}
 
 // byte offset of channel c (multiple of 4) of pixel `pix` inside an image with 128-byte pixel rows
 __device__ __forceinline__ int swz(int pix, int c) {
@@ -55,7 +71,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void wgrad3x3_tile_kernel(WgTilePar
     unsigned char* dyl = lds;
     unsigned char* xl = lds + DY_BYTES;
 
-    const int pair = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    int pair, split;
+    wg_decode(p, pair, split);
+    const int nsplit = p.nsplit;
     const int cob = pair / p.ci_blocks, cib = pair - cob * p.ci_blocks;
     const int co0 = cob * BO, ci0 = cib * BI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -225,8 +243,10 @@ int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, 
     p.N = d->n; p.H = d->h; p.W = d->w; p.Cin = d->cin; p.Cout = d->cout; p.ld_x = d->in_ld; p.ld_dy = d->out_ld;
     p.tiles_x = ur_cdiv(d->w, TW); p.tiles_y = ur_cdiv(d->h, tile_rows()); p.tiles = pl.tiles;
     p.ci_blocks = d->cin / BI;
-    if (tile_rows() == 4) hipLaunchKernelGGL((wgrad3x3_tile_kernel<4, 1>), dim3(pl.pairs, pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
-    else hipLaunchKernelGGL((wgrad3x3_tile_kernel<2, 2>), dim3(pl.pairs, pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
+    p.pairs = pl.pairs; p.nsplit = pl.nsplit;
+    p.xcd_order = pl.nsplit % 8 == 0;
+    if (tile_rows() == 4) hipLaunchKernelGGL((wgrad3x3_tile_kernel<4, 1>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL((wgrad3x3_tile_kernel<2, 2>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
     if (int e = ur_check_launch("wgrad3x3_tile")) return e;
     const long long per = (long long)d->cout * 9 * d->cin;
     if (ur_slab_lanes(pl.nsplit) == 32)
