@@ -349,27 +349,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
 //   forward : value = w[co = nb*64 + b*32 + (lane&31)][ci = chunk*16 + 8*(lane>>5) + j][tap]
 //   dgrad   : the kernel convolves dy (channels = cout of the layer) into dx (channels = cin):
 //             value = w[co = chunk*16 + 8*(lane>>5) + j][ci = nb*64 + b*32 + (lane&31)][8 - tap]
-__global__ void pack_tile_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int cin, int cout,
-                                         int dgrad) {
+// One (64 produced channels) x (16 reduced channels) x 9 taps block of the image = 18 KiB of contiguous output.  Its
+// source is 64 runs of 144 floats (forward) or 16 runs of 576 floats (dgrad): read coalesced into LDS, written
+// back as 16-byte pieces in fragment order.
+constexpr int PACK_BLOCK = BN * KC * 9;
+__device__ __forceinline__ void pack_tile_weights_body(const float* __restrict__ w, bf16_t* __restrict__ dst, int cin, int cout,
+                                                        int dgrad, int first, int step, float* tile) {
     const int rows = dgrad ? cin : cout;      // channels produced by the kernel
     const int red = dgrad ? cout : cin;       // channels reduced over
     const int chunks = red / KC;
-    const long long total = (long long)(rows / BN) * chunks * W_PIECES * 8;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 7);
-        const int lane = (int)((i >> 3) & 63);
-        long long t = i >> 9;
-        const int b = (int)(t & 1); t >>= 1;
-        const int tap = (int)(t % 9); t /= 9;
-        const int chunk = (int)(t % chunks);
-        const int nb = (int)(t / chunks);
-        const int n = nb * BN + b * 32 + (lane & 31);
-        const int k = chunk * KC + 8 * (lane >> 5) + j;
-        float v;
-        if (!dgrad) v = w[((size_t)n * cin + k) * 9 + tap];
-        else v = w[((size_t)k * cin + n) * 9 + (8 - tap)];
-        dst[i] = (bf16_t)v;
+    const int nblocks = (rows / BN) * chunks;
+    for (int blk = first; blk < nblocks; blk += step) {
+        const int nb = blk / chunks, chunk = blk - nb * chunks;
+        if (!dgrad) {
+            for (int i = threadIdx.x; i < PACK_BLOCK; i += blockDim.x) {
+                const int n = i / (KC * 9), rem = i - n * (KC * 9);
+                tile[i] = w[((size_t)(nb * BN + n) * cin + chunk * KC) * 9 + rem];
+            }
+        } else {
+            for (int i = threadIdx.x; i < PACK_BLOCK; i += blockDim.x) {
+                const int k = i / (BN * 9), rem = i - k * (BN * 9);
+                tile[i] = w[((size_t)(chunk * KC + k) * cin + nb * BN) * 9 + rem];
+            }
+        }
+        __syncthreads();
+        for (int pi = threadIdx.x; pi < PACK_BLOCK / 8; pi += blockDim.x) {
+            const int lane = pi & 63, t = pi >> 6, b = t & 1, tap = t >> 1;
+            const int n = b * 32 + (lane & 31), k0 = 8 * (lane >> 5);
+            bf16x8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = (bf16_t)(dgrad ? tile[(k0 + j) * (BN * 9) + n * 9 + (8 - tap)] : tile[n * (KC * 9) + (k0 + j) * 9 + tap]);
+            *reinterpret_cast<bf16x8_t*>(dst + ((size_t)blk * (PACK_BLOCK / 8) + pi) * 8) = o;
+        }
+        __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void pack_tile_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int cin,
+                                                                int cout, int dgrad) {
+    __shared__ float tile[PACK_BLOCK];
+    pack_tile_weights_body(w, dst, cin, cout, dgrad, blockIdx.x, gridDim.x, tile);
+}
+
+// Many layers in one launch: table[e] = {w, dst, cin, cout, dgrad} (64-bit words), workgroups (x, e) walk entry e
+__global__ __launch_bounds__(256) void pack_tile_weights_multi_kernel(const long long* __restrict__ table) {
+    __shared__ float tile[PACK_BLOCK];
+    const long long* row = table + 5 * (long long)blockIdx.y;
+    pack_tile_weights_body(reinterpret_cast<const float*>(row[0]), reinterpret_cast<bf16_t*>(row[1]), (int)row[2], (int)row[3],
+                           (int)row[4], blockIdx.x, gridDim.x, tile);
 }
 
 int check(const ur_conv_desc* d, bool dgrad) {
@@ -434,9 +462,17 @@ int ur_conv3x3_tile_pack_weight(const float* w, void* packed, const ur_conv_desc
     if (int e = check(d, dgrad != 0)) return e;
     UR_REQUIRE(w && packed, "conv3x3_tile_pack_weight: null pointer");
     const long long total = (long long)d->cin * d->cout * 9;
-    hipLaunchKernelGGL(pack_tile_weights_kernel, dim3(ur_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)s, w,
+    hipLaunchKernelGGL(pack_tile_weights_kernel, dim3(ur_grid_1d(total, PACK_BLOCK, 2048)), dim3(256), 0, (hipStream_t)s, w,
                        (bf16_t*)packed, d->cin, d->cout, dgrad != 0);
     return ur_check_launch("pack_tile_weights");
+}
+
+int ur_conv3x3_tile_pack_weights_multi(const long long* table, int entries, long long max_elems, ur_stream_t s) {
+    UR_REQUIRE(table && entries > 0 && entries <= 65535 && max_elems > 0, "conv3x3_tile_pack_weights_multi: bad arguments");
+    // workgroups per entry sized for the largest one (one 64 x 16 x 9 block each); smaller entries finish early
+    hipLaunchKernelGGL(pack_tile_weights_multi_kernel, dim3(ur_grid_1d(max_elems, PACK_BLOCK, 512), entries), dim3(256), 0,
+                       (hipStream_t)s, table);
+    return ur_check_launch("pack_tile_weights_multi");
 }
 
 int ur_conv3x3_tile_stats_rows(const ur_conv_desc* d) {

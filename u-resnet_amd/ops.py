@@ -7,6 +7,7 @@ kernels.  Parameters and their gradients are fp32 in PyTorch's native layouts, s
 state_dicts are interchangeable with the reference's.
 """
 import ctypes as C
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -189,6 +190,41 @@ def _desc(x_shape, cout, kh, kw, stride, pad, dtype, oh=None, ow=None):
     return d
 
 
+batch_repack = True         # False: one packing launch per layer and direction (A/B comparisons)
+_tile_images = []          # (weakref(PackedWeights), mode, weakref(weight)) of every tile-kernel weight image made so far
+_tile_table = [None, None]  # (rows, device table) of the last batched repack
+
+
+def _repack_stale_tile_images(device):
+    """After an optimiser step every cached tile-kernel weight image is stale at once: rebuild them all with one
+    launch (in place, the images keep their storage) instead of one launch per layer and direction."""
+    rows, hits, live = [], [], []
+    for ref, mode, wref in _tile_images:
+        pw, w = ref(), wref()
+        if pw is None or w is None:
+            continue
+        live.append((ref, mode, wref))
+        hit = pw._cache.get(mode)
+        if hit is None or not w.is_cuda or w.device != device or w.dtype != torch.float32 or not w.is_contiguous():
+            continue
+        key, packed = hit
+        new_key = (w.data_ptr(), w._version, _weights_epoch) + key[3:]
+        if key == new_key or key[0] != new_key[0]:
+            continue
+        rows.append((w.data_ptr(), packed.data_ptr(), key[4], key[5], int(mode == "tile_dgrad")))
+        hits.append((pw, mode, new_key, packed))
+    _tile_images[:] = live
+    if not rows:
+        return
+    if _tile_table[0] != rows:
+        _tile_table[0] = rows
+        _tile_table[1] = torch.tensor(rows, dtype=torch.int64).to(device)
+    call("ur_conv3x3_tile_pack_weights_multi", _tile_table[1].data_ptr(), len(rows), max(r[2] * r[3] * 9 for r in rows),
+         _stream())
+    for pw, mode, new_key, packed in hits:
+        pw._cache[mode] = (new_key, packed)
+
+
 class PackedWeights:
     """Per-layer cache of the weight matrices the GEMM kernels consume (activation dtype, k-major)."""
 
@@ -202,8 +238,15 @@ class PackedWeights:
         hit = self._cache.get(mode)
         if hit is not None and hit[0] == key:
             return hit[1]
+        if batch_repack and hit is not None and hit[0][0] == key[0] and hit[0][3:] == key[3:]:
+            _repack_stale_tile_images(weight.device)           # same parameter, new values
+            hit = self._cache.get(mode)
+            if hit[0] == key:
+                return hit[1]
         packed = torch.empty(query("ur_conv3x3_tile_packed_elems", C.byref(d)), dtype=torch.bfloat16, device=weight.device)
         call("ur_conv3x3_tile_pack_weight", weight.data_ptr(), packed.data_ptr(), C.byref(d), int(dgrad), _stream())
+        if hit is None:
+            _tile_images.append((weakref.ref(self), mode, weakref.ref(weight)))
         self._cache[mode] = (key, packed)
         return packed
 
