@@ -84,8 +84,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     uresnet_amd._lib.load()
-    if os.environ.get("URESNET_BATCH_PACK") == "0":
+    if os.environ.get("URESNET_BATCH_PACK") == "0":          # A/B switches of two fusions
         ops.batch_repack = False
+    if os.environ.get("URESNET_POOL_SKIP") == "0":
+        uresnet_amd.modules._blocks.fuse_pool_skip = False
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)

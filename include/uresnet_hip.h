@@ -169,8 +169,11 @@ int ur_bn_act_bwd_apply(const void* dz, const void* y, const void* z, const floa
 /* x_ld: channel pitch of x in elements (0 or c: dense) -- x may be a channel window of a wider NHWC tensor */
 int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, int h, int w, int c, int x_ld,
                       ur_stream_t s);
-int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int n, int h, int w, int c,
-                      ur_stream_t s);
+/* dx = scatter(dy) (+ addend): `addend` (NULL: none; add_ld = its channel pitch, 0 or c: dense) is the second
+ * gradient of the pooled tensor when it also feeds a skip connection (S/C:270-279), summed here instead of by
+ * a separate add */
+int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, const void* addend, int add_ld, int dtype, int n,
+                      int h, int w, int c, ur_stream_t s);
 int ur_upsample_bilinear_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c, int scale,
                              ur_stream_t s);
 int ur_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int n, int h, int w, int c, int scale,

@@ -533,6 +533,28 @@ def test_feature_merge_windows_are_bit_exact(pkg):
         ops.cat_windows(wb, wa, buf)
 
 
+def test_maxpool_skip_sums_both_gradients_in_kernel(pkg):
+    """maxpool2x2_skip(x) = (maxpool2x2(x), x); its backward equals maxpool backward + the skip gradient (bit-exact),
+    for dense and channel-window inputs and gradients, odd sizes included."""
+    ops = pkg.ops
+    torch.manual_seed(4)
+    for dtype in (torch.bfloat16, torch.float32):
+        for (n, c, h, w) in ((2, 16, 12, 20), (1, 8, 7, 9)):
+            x = ops.as_activation(torch.randn(n, c, h, w, device=DEV), dtype).requires_grad_(True)
+            gp = ops.as_activation(torch.randn(n, c, h // 2, w // 2, device=DEV), dtype)
+            wide = ops.as_activation(torch.randn(n, c + 8, h, w, device=DEV), dtype)
+            for gs in (ops.as_activation(torch.randn(n, c, h, w, device=DEV), dtype), wide[:, :c]):
+                ref_p = ops.maxpool2x2(x)
+                (ref_dx,) = torch.autograd.grad(ref_p, x, gp)
+                ref_dx = ref_dx + ops.dense(gs) if not ops._is_nhwc_dense(gs) else ref_dx + gs
+                p, skip = ops.maxpool2x2_skip(x)
+                assert torch.equal(p, ref_p) and skip.data_ptr() == x.data_ptr() and torch.equal(skip, x)
+                (dx,) = torch.autograd.grad((p, skip), x, (gp, gs))
+                assert torch.equal(dx, ref_dx)
+            (dx,) = torch.autograd.grad(ops.maxpool2x2_skip(x)[0], x, gp)          # skip unused
+            assert torch.equal(dx, torch.autograd.grad(ops.maxpool2x2(x), x, gp)[0])
+
+
 def test_seg_model_ragged_size_matches_oracle(pkg, oracle):
     """36 x 52 input: level 3 is 9 x 13, so that Up block pads (unfused path) while the others write the skip tensor
     and the transposed convolution straight into the concatenated tensor."""

@@ -67,7 +67,7 @@ SIGNATURES = {
     "ur_bn_bwd_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ur_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _ll, _i, _i, _vp]),
     "ur_maxpool2x2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ur_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ur_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_upsample_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_upsample_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_avgpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

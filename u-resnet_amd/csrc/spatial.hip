@@ -63,7 +63,8 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
 
 template <typename T, int V>
 __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
-                                                         T* __restrict__ dx, int N, int H, int W, int C) {
+                                                         T* __restrict__ dx, const T* __restrict__ addend, int add_ld, int N,
+                                                         int H, int W, int C) {
     const int OH = H / 2, OW = W / 2, CV = C / V;
     const unsigned total = (unsigned)N * H * W * CV;
     GRID_STRIDE(i, total) {
@@ -80,6 +81,11 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ d
             const int me = (iy & 1) * 2 + (ix & 1);
 #pragma unroll
             for (int k = 0; k < V; ++k) o.v[k] = idx[op + k] == me ? g.v[k] : 0.f;
+        }
+        if (addend) {                                   // a second gradient of the pooled tensor (its skip connection)
+            Pack<T, V> a; a.load(addend + (size_t)pix * add_ld + cv * V);
+#pragma unroll
+            for (int k = 0; k < V; ++k) o.v[k] += a.v[k];
         }
         o.store(dx + (size_t)pix * C + cv * V);
     }
@@ -347,12 +353,16 @@ int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, in
     return ur_check_launch("maxpool_fwd");
 }
 
-int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int n, int h, int w, int c, ur_stream_t s) {
+int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, const void* addend, int add_ld, int dtype, int n, int h,
+                      int w, int c, ur_stream_t s) {
     UR_REQUIRE(dy && dx && idx && n > 0 && h >= 2 && w >= 2 && c > 0, "maxpool_bwd: bad arguments");
-    const bool vec = c % 4 == 0 && al(dy, 4 * esize(dtype)) && al(dx, 4 * esize(dtype));
+    if (add_ld == 0) add_ld = c;
+    UR_REQUIRE(!addend || add_ld >= c, "maxpool_bwd: addend pitch %d is smaller than the channel count %d", add_ld, c);
+    const bool vec = c % 4 == 0 && al(dy, 4 * esize(dtype)) && al(dx, 4 * esize(dtype)) &&
+                     (!addend || (al(addend, 4 * esize(dtype)) && add_ld % 4 == 0));
     const long long total = (long long)n * h * w * c;
     UR_REQUIRE_32BIT(total, "maxpool_bwd");
-    SPATIAL_LAUNCH(maxpool_bwd_kernel, total, (const T*)dy, idx, (T*)dx, n, h, w, c);
+    SPATIAL_LAUNCH(maxpool_bwd_kernel, total, (const T*)dy, idx, (T*)dx, (const T*)addend, add_ld, n, h, w, c);
     return ur_check_launch("maxpool_bwd");
 }
 

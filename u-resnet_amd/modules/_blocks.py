@@ -6,6 +6,8 @@ Containers run a fused schedule (conv with BN statistics in its epilogue, then o
 normalise+residual+ReLU pass); when a forward hook is registered on any child they run child by
 child instead, so feature-map hooks see every intermediate tensor.
 """
+import torch
+
 from .. import _lib, ops
 from .. import nn as hnn
 from ..nn import act_dtype, conv_bn_act, has_hooks
@@ -295,10 +297,11 @@ def add_unet_branch(m, in_channels, base_c, levels=4):
         setattr(m, 'down%d' % (i + 1), Down(base_c << i, base_c << (i + 1)))
 
 
-def _skip_into_cat(block, x, up):
+def _skip_into_cat(block, x, up, pooled=None):
     """Run the encoder stage `block` (DoubleConv or Down) on x and return (skip, cat): when possible the stage's last
     BatchNorm+ReLU writes the skip tensor straight into the first channel window of the tensor that `up` will
-    concatenate it into (cat, else None), which removes the copy of the skip half of torch.cat (S/C:119-124)."""
+    concatenate it into (cat, else None), which removes the copy of the skip half of torch.cat (S/C:119-124).
+    pooled: the Down stage's max-pool result when the caller has already computed it (_pool_and_skip)."""
     down = isinstance(block, Down)
     dc = block[1] if down else block
     fused = (isinstance(dc, DoubleConv) and isinstance(up, Up) and not has_hooks(block, up, up.up, *dc)
@@ -311,23 +314,41 @@ def _skip_into_cat(block, x, up):
         # the level below halves (floor) and the transposed convolution doubles: sizes must be even to line up
         fused = h % 2 == 0 and w % 2 == 0 and h > 0 and w > 0 and up.conv[0].in_channels == c_skip + c_up
     if not fused:
+        if pooled is not None:
+            return block[1](pooled), None
         return block(x), None
     dtype = act_dtype(x)
     cat = ops.empty_nhwc(n, c_skip + c_up, h, w, dtype, x.device)
     win = ops.alias_window(cat, 0, c_skip)
-    skip = dc(block[0](x), out=win) if down else dc(x, out=win)
+    skip = dc(block[0](x) if pooled is None else pooled, out=win) if down else dc(x, out=win)
     if skip.data_ptr() != win.data_ptr():          # the block could not honour the window
         return skip, None
     return skip, cat
 
 
+fuse_pool_skip = True       # False: separate max-pool and gradient add (A/B comparisons)
+
+
+def _pool_and_skip(down, x):
+    """(max-pooled x for the stage `down`, x for the skip connection).  Without hooks both come from one operator whose
+    backward sums the two gradients of x inside the pooling kernel; otherwise (None, x)."""
+    if (fuse_pool_skip and isinstance(down, Down) and not has_hooks(down, down[0]) and x.is_cuda and x.dim() == 4
+            and x.dtype in (torch.float32, torch.bfloat16) and x.requires_grad and ops._channel_pitch(x)):
+        return ops.maxpool2x2_skip(x)
+    return None, x
+
+
 def unet_branch_forward(m, x, out=None):
     """out: optional channel window for the branch's result (see Up.forward)."""
     x1, c1 = _skip_into_cat(m.in_conv, x, m.up4)
-    x2, c2 = _skip_into_cat(m.down1, x1, m.up3)
-    x3, c3 = _skip_into_cat(m.down2, x2, m.up2)
-    x4, c4 = _skip_into_cat(m.down3, x3, m.up1)
-    x5 = m.down4(x4)
+    p1, x1 = _pool_and_skip(m.down1, x1)
+    x2, c2 = _skip_into_cat(m.down1, x1, m.up3, p1)
+    p2, x2 = _pool_and_skip(m.down2, x2)
+    x3, c3 = _skip_into_cat(m.down2, x2, m.up2, p2)
+    p3, x3 = _pool_and_skip(m.down3, x3)
+    x4, c4 = _skip_into_cat(m.down3, x3, m.up1, p3)
+    p4, x4 = _pool_and_skip(m.down4, x4)
+    x5 = m.down4(x4) if p4 is None else m.down4[1](p4)
     u = m.up1(x5, x4, c4)
     u = m.up2(u, x3, c3)
     u = m.up3(u, x2, c2)

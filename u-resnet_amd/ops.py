@@ -686,12 +686,54 @@ class _MaxPool2x2(Function):
         n, c, h, w = ctx.shape
         dy = _g(dy)
         dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
-        call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _dt(dy), n, h, w, c, _stream())
+        call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), None, 0, _dt(dy), n, h, w, c, _stream())
         return dx
 
 
 def maxpool2x2(x):
     return _MaxPool2x2.apply(x)
+
+
+class _MaxPool2x2Skip(Function):
+    """x -> (maxpool2x2(x), x): the second output aliases x and goes to the skip connection, so that both gradients of
+    x arrive in one backward call and are summed inside the pooling backward kernel (no separate add pass)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
+        idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
+        call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _channel_pitch(x) or c,
+             _stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, c, h, w)
+        ctx.set_materialize_grads(False)
+        skip = torch.empty(0, dtype=x.dtype, device=x.device)
+        skip.set_(x.untyped_storage(), x.storage_offset(), x.size(), x.stride())
+        return y, skip
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        if dy is None:
+            return dskip
+        dy = _g(dy)
+        add_ld = 0
+        if dskip is not None:
+            add_ld = _channel_pitch(dskip) if (dskip.is_cuda and dskip.dtype == dy.dtype) else 0
+            if not add_ld:
+                dskip, add_ld = _g(dskip), c
+        dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
+        call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _p(dskip), add_ld, _dt(dy), n, h, w, c,
+             _stream())
+        return dx
+
+
+def maxpool2x2_skip(x):
+    """(maxpool2x2(x), alias of x for the skip connection); x: dense NHWC or a channel window."""
+    return _MaxPool2x2Skip.apply(x)
 
 
 class _UpsampleBilinear(Function):
