@@ -88,6 +88,8 @@ def main():
         ops.batch_repack = False
     if os.environ.get("URESNET_POOL_SKIP") == "0":
         uresnet_amd.modules._blocks.fuse_pool_skip = False
+    if os.environ.get("URESNET_RES_GRAD") == "0":
+        uresnet_amd.modules._blocks.fuse_residual_grad = False
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)

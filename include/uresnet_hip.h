@@ -90,6 +90,11 @@ int ur_conv3x3_tile_fwd(const void* x, const void* w_packed, void* y, float* sta
                         ur_stream_t s);
 int ur_conv3x3_tile_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const ur_conv_desc* d,
                           ur_stream_t s);
+/* dx = round(conv_backward_input(dy)) + addend: the input of a residual block (S/C:156-159) has a second gradient
+ * from the shortcut; it is added in the epilogue (same rounding as a separate add of the two bf16 tensors).
+ * add_ld = channel pitch of addend in elements (0 or cin: dense). */
+int ur_conv3x3_tile_dgrad_add(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
+                              const ur_conv_desc* d, ur_stream_t s);
 
 /* backward-weight counterpart (same contract as ur_conv2d_wgrad; needs 64 | cin and 64 | cout) */
 int ur_wgrad3x3_tile_supported(const ur_conv_desc* d);

@@ -555,6 +555,30 @@ def test_maxpool_skip_sums_both_gradients_in_kernel(pkg):
             assert torch.equal(dx, torch.autograd.grad(ops.maxpool2x2(x), x, gp)[0])
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (32, 32)])
+def test_residual_gradient_in_dgrad_epilogue_is_bit_exact(pkg, cin, cout):
+    """BasicBlock with the shortcut gradient added inside the first convolution's backward-data kernel (tile kernel for
+    64 | cin, separate in-place add otherwise) == the block with autograd's own gradient add."""
+    blocks = pkg.modules._blocks
+    torch.manual_seed(12)
+    blk = blocks.BasicBlock(cin, cout).to(DEV).train()
+    x0 = pkg.ops.as_activation(torch.randn(2, cin, 16, 32, device=DEV), torch.bfloat16)
+    g = pkg.ops.as_activation(torch.randn(2, cout, 16, 32, device=DEV), torch.bfloat16)
+    results = []
+    for fused in (False, True):
+        blocks.fuse_residual_grad = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = blk(x)
+            grads = torch.autograd.grad(y, [x] + list(blk.parameters()), g)
+        finally:
+            blocks.fuse_residual_grad = True
+        results.append((y.detach(), grads))
+    assert torch.equal(results[0][0], results[1][0])
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)
+
+
 def test_seg_model_ragged_size_matches_oracle(pkg, oracle):
     """36 x 52 input: level 3 is 9 x 13, so that Up block pads (unfused path) while the others write the skip tensor
     and the transposed convolution straight into the concatenated tensor."""

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ur_conv3x3_tile_stats_rows": (_i, [_dp]),
     "ur_conv3x3_tile_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
+    "ur_conv3x3_tile_dgrad_add": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _vp]),
     "ur_wgrad3x3_tile_supported": (_i, [_dp]),
     "ur_wgrad3x3_tile_workspace": (_sz, [_dp]),
     "ur_wgrad3x3_tile": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),

@@ -54,6 +54,8 @@ struct TileParams {
     const bf16_t* wpk;    // [Cout/64][Cin/16][9][2][64][8]
     bf16_t* y;            // [N][H][W][ld_out]
     float* stats;         // [tiles][Cout][2] or null
+    const bf16_t* addend; // [N][H][W][ld_add] or null: added to the rounded result (a second gradient of the same tensor)
+    int ld_add;
     int N, H, W, Cin, Cout;
     int ld_in, ld_out;
     int tiles_x, tiles_y, tiles;     // spatial tiles per image row / column / total (N * ty * tx)
@@ -325,9 +327,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
         const int idx = lane + 64 * i;
         const int pxl = idx >> 3, piece = idx & 7;
         const int oy = ty0 + wave * R + (pxl >> 5), ox = tx0 + (pxl & 31);
-        if (oy < p.H && ox < p.W)
-            *reinterpret_cast<float4*>(p.y + ((size_t)(img * p.H + oy) * p.W + ox) * p.ld_out + nb * BN + piece * 8) =
-                *reinterpret_cast<const float4*>(ostage + pxl * OUT_PITCH + piece * 16);
+        if (oy < p.H && ox < p.W) {
+            const size_t pix = (size_t)(img * p.H + oy) * p.W + ox;
+            bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ostage + pxl * OUT_PITCH + piece * 16);
+            if (p.addend) {
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (bf16_t)((float)v[k] + (float)a[k]);
+            }
+            *reinterpret_cast<bf16x8_t*>(p.y + pix * p.ld_out + nb * BN + piece * 8) = v;
+        }
     }
     if (p.stats) {
 #pragma unroll
@@ -425,11 +434,13 @@ int pick_rows(const ur_conv_desc* d, bool dgrad) {
     return (wgs4 >= 1024 || wgs4 % 512 == 0) ? 4 : 2;
 }
 
-int launch(const void* src, const void* wpk, void* dst, float* stats, const ur_conv_desc* d, bool dgrad, hipStream_t st) {
+int launch(const void* src, const void* wpk, void* dst, float* stats, const ur_conv_desc* d, bool dgrad, hipStream_t st,
+           const void* addend = nullptr, int add_ld = 0) {
     const int R = pick_rows(d, dgrad);
     const int TH = 4 * R;
     TileParams p{};
     p.x = (const bf16_t*)src; p.wpk = (const bf16_t*)wpk; p.y = (bf16_t*)dst; p.stats = stats;
+    p.addend = (const bf16_t*)addend; p.ld_add = add_ld;
     p.N = d->n; p.H = d->h; p.W = d->w;
     p.Cin = dgrad ? d->cout : d->cin; p.Cout = dgrad ? d->cin : d->cout;
     p.ld_in = dgrad ? d->out_ld : d->in_ld; p.ld_out = dgrad ? d->in_ld : d->out_ld;
@@ -489,6 +500,17 @@ int ur_conv3x3_tile_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, 
     if (int e = check(d, true)) return e;
     UR_REQUIRE(dy && w_packed_dgrad && dx, "conv3x3_tile_dgrad: null pointer");
     return launch(dy, w_packed_dgrad, dx, nullptr, d, true, (hipStream_t)s);
+}
+
+int ur_conv3x3_tile_dgrad_add(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
+                              const ur_conv_desc* d, ur_stream_t s) {
+    if (int e = check(d, true)) return e;
+    UR_REQUIRE(dy && w_packed_dgrad && dx && addend, "conv3x3_tile_dgrad_add: null pointer");
+    if (add_ld == 0) add_ld = d->cin;
+    UR_REQUIRE(add_ld >= d->cin && add_ld % 8 == 0 && ((uintptr_t)addend % 16) == 0,
+               "conv3x3_tile_dgrad_add: addend pitch %d must be a multiple of 8 >= %d and the pointer 16-byte aligned", add_ld, d->cin);
+    UR_REQUIRE((long long)d->n * d->h * d->w * add_ld < (1LL << 31), "conv3x3_tile_dgrad_add: addend exceeds 2^31 elements");
+    return launch(dy, w_packed_dgrad, dx, nullptr, d, true, (hipStream_t)s, addend, add_ld);
 }
 
 }  // extern "C"

@@ -214,8 +214,14 @@ class BasicBlock(hnn.Module):
         if has_hooks(self.left, *self.left, self.shortcut, *self.shortcut):
             out = ops.add(self.left(x), self.shortcut(x))
             return ops.activation(out, _lib.ACT_RELU)
-        out = _cba(self.left, x, 0)
-        sc = x if len(self.shortcut) == 0 else conv_bn_act(x, self.shortcut[0], self.shortcut[1], _lib.ACT_NONE)
+        if fuse_residual_grad and x.requires_grad and x.is_cuda and self.left[0].groups == 1:
+            # the shortcut reads an alias of x handed out by the first convolution, whose backward-data kernel then
+            # adds the shortcut's gradient in its epilogue
+            y, stats, xs = self.left[0].raw(x, want_stats=self.left[1].training, want_alias=True)
+            out = ops.bn_act(y, self.left[1], stats=stats, act=_lib.ACT_RELU)
+        else:
+            out, xs = _cba(self.left, x, 0), x
+        sc = xs if len(self.shortcut) == 0 else conv_bn_act(xs, self.shortcut[0], self.shortcut[1], _lib.ACT_NONE)
         # second conv's BN, the residual add and the final ReLU are one pass
         return conv_bn_act(out, self.left[3], self.left[4], _lib.ACT_RELU, residual=sc)
 
@@ -327,6 +333,7 @@ def _skip_into_cat(block, x, up, pooled=None):
 
 
 fuse_pool_skip = True       # False: separate max-pool and gradient add (A/B comparisons)
+fuse_residual_grad = True   # False: the two gradients of a residual block's input are summed by a separate add
 
 
 def _pool_and_skip(down, x):

@@ -58,14 +58,16 @@ class Conv2d(tnn.Conv2d):
                 raise NotImplementedError("grouped Conv2d: only 3x3/s1/p1, in==out channels, 1 or 4 channels per "
                                           "group, no bias (the EUCB / EUCB* layers) is implemented")
 
-    def raw(self, x, want_stats=False, out=None):
+    def raw(self, x, want_stats=False, out=None, want_alias=False):
         """(y, stats) -- stats are the per-channel partial sums for a following training-mode BatchNorm.  `out`:
         optional channel window (ops.alias_window) for y, honoured by the dense convolutions only (callers compare
         data_ptr())."""
         x = ops.as_activation(x, act_dtype(x))
         if self.groups != 1:
+            if want_alias:
+                raise NotImplementedError("grouped Conv2d has no input alias")
             return ops.gconv3x3(x, self.weight), None
-        return ops.conv2d(x, self.weight, self.bias, self._packs, self._s, self._p, want_stats, out)
+        return ops.conv2d(x, self.weight, self.bias, self._packs, self._s, self._p, want_stats, out, want_alias)
 
     def forward(self, x):
         return self.raw(x)[0]

@@ -338,8 +338,9 @@ def _crop_channels(x, c):
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packs, stride, pad, want_stats, out):
+    def forward(ctx, x, weight, bias, packs, stride, pad, want_stats, out, want_alias):
         _require_gpu(x)
+        x_in = x
         cout, cin, kh, kw = weight.shape
         if x.shape[1] != cin:
             raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], cin))
@@ -379,15 +380,20 @@ class _Conv2d(Function):
         ctx.save_for_backward(x, weight)          # x: as the kernel saw it (channel-padded on the generic path)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
         ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
+        # alias of the input for a second consumer (the shortcut of a residual block): its gradient comes back to this
+        # node and is added in the backward-data epilogue instead of by a separate add
+        alias = None
+        if want_alias:
+            alias = torch.empty(0, dtype=x_in.dtype, device=x_in.device)
+            alias.set_(x_in.untyped_storage(), x_in.storage_offset(), x_in.size(), x_in.stride())
         if want_stats:
             ctx.mark_non_differentiable(stats)
-            return y, stats
-        return y, None
+        return y, stats if want_stats else None, alias
 
     @staticmethod
-    def backward(ctx, dy, _dstats):
+    def backward(ctx, dy, _dstats, dalias):
         if dy is None:
-            return None, None, None, None, None, None, None, None
+            return dalias, None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         d = ctx.d
         cout, cin = weight.shape[0], weight.shape[1]
@@ -412,14 +418,25 @@ class _Conv2d(Function):
             dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
             if tile_d:
                 wp = ctx.packs.get_tile(weight, d, True)
+                add_ld = 0
+                if dalias is not None and dalias.dtype == x.dtype and dalias.data_ptr() % 16 == 0:
+                    add_ld = _channel_pitch(dalias)
                 with _Timed("tile_dgrad", _conv_flops(d), d):
-                    call("ur_conv3x3_tile_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+                    if add_ld and add_ld % 8 == 0:
+                        call("ur_conv3x3_tile_dgrad_add", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), dalias.data_ptr(), add_ld,
+                             C.byref(d), _stream())
+                        dalias = None
+                    else:
+                        call("ur_conv3x3_tile_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
             else:
                 wp = ctx.packs.get(weight, d, _lib.PACK_DGRAD)
                 with _Timed("igemm_dgrad", _conv_flops(d), d):
                     call("ur_conv2d_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
             if d.cin != cin:
                 dx = _crop_channels(dx, cin)
+            if dalias is not None:
+                dalias = _g(dalias)
+                call("ur_add_inplace", dx.data_ptr(), dalias.data_ptr(), _dt(dx), dx.numel(), _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty((d.cout, d.cin, d.kh, d.kw), dtype=weight.dtype, device=weight.device)
             if tile_w:
@@ -434,12 +451,16 @@ class _Conv2d(Function):
                          C.byref(d), _stream())
             if (d.cout, d.cin) != (cout, cin):
                 dw = dw[:cout, :cin].contiguous()
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, packs, stride=1, pad=0, want_stats=False, out=None):
-    """`out`: optional channel window (alias_window) that receives the result."""
-    return _Conv2d.apply(x, weight, bias, packs, stride, pad, want_stats, None if out is None else (out,))
+def conv2d(x, weight, bias, packs, stride=1, pad=0, want_stats=False, out=None, want_alias=False):
+    """(y, stats or None[, alias]).  `out`: optional channel window (alias_window) that receives the result.
+    want_alias: also return an alias of x for a second consumer, whose gradient is then summed in this convolution's
+    backward-data kernel."""
+    y, stats, alias = _Conv2d.apply(x, weight, bias, packs, stride, pad, want_stats, None if out is None else (out,),
+                                    want_alias)
+    return (y, stats, alias) if want_alias else (y, stats)
 
 
 class _ConvT2x2(Function):
