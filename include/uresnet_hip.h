@@ -235,6 +235,16 @@ int ur_argmax_channels(const void* logits, int dtype, long long rows, int classe
                        ur_stream_t s);
 /* out = sigmoid(x) > 0.5 evaluated in fp32 as the reference writes it */
 int ur_sigmoid_mask(const void* logits, int dtype, long long count, uint8_t* out, ur_stream_t s);
+/* Validation metrics of train_UResNetAblitionStudy.py:70-100 without leaving the GPU.
+ * cm[t * classes + p] += 1 for every pixel with target t != ignore_index (0 <= t < classes) and p = argmax(logits)
+ * (same first-maximum rule as ur_argmax_channels); cm is 64-bit and accumulates across calls. */
+int ur_confusion_matrix(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
+                        long long ignore_index, unsigned long long* cm, ur_stream_t s);
+/* acc7 += (precision, recall, accuracy, f1, iou, 1, *loss) of one confusion matrix: macro averages over the labels
+ * present in targets or predictions, zero denominators score 0 (sklearn average='macro', zero_division=0; :82-89).
+ * Dividing acc7[0..4] and acc7[6] by acc7[5] gives the per-batch means that validate() reports (:144-162).
+ * loss: device scalar of the batch (NULL: none). */
+int ur_seg_metrics_accumulate(const unsigned long long* cm, int classes, const float* loss, double* acc7, ur_stream_t s);
 
 /* ---------------------------------------------------------------- optimisers (multi-tensor)
  * optim.Adam(lr) (train_UResNetAblitionStudy.py:203) and optim.SGD(lr) (CNN-CIFAR10.py:130).

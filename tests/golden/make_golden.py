@@ -130,6 +130,41 @@ def loss_case():
     print("wrote losses_masks")
 
 
+def metrics_case():
+    """calculate_metrics (train_UResNetAblitionStudy.py:70-100).  The script itself cannot be imported (it needs
+    albumentations / the dataset package at import time), so the function's definition is compiled on its own from the
+    script's syntax tree and run with the sklearn functions it names."""
+    import ast
+    from sklearn.metrics import accuracy_score, f1_score, jaccard_score, precision_score, recall_score
+    path = os.path.join(REF, "Segmentation/Cityscapes/train_UResNetAblitionStudy.py")
+    tree = ast.parse(open(path, encoding="utf-8").read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "calculate_metrics"]
+    ns = dict(precision_score=precision_score, recall_score=recall_score, accuracy_score=accuracy_score,
+              f1_score=f1_score, jaccard_score=jaccard_score)
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    ref_metrics = ns["calculate_metrics"]
+    keys = ("precision", "recall", "accuracy", "f1", "iou", "dice")
+    g = torch.Generator().manual_seed(21)
+    rec = {}
+    # 0: all 19 classes; 1: targets use 6 classes, predictions 8 (absent labels, zero divisions); 2: one pixel class only
+    for i in range(3):
+        logits = torch.randn(2, 19, 16, 32, generator=g)
+        tgt = torch.randint(0, 19, (2, 16, 32), generator=g)
+        if i == 1:
+            logits[:, 8:] -= 50.0
+            tgt = torch.randint(0, 6, (2, 16, 32), generator=g)
+        if i == 2:
+            tgt = torch.full((2, 16, 32), 4)
+            logits[:, 4] += 2.0
+        tgt[torch.rand(2, 16, 32, generator=g) < 0.1] = 255
+        m = ref_metrics(logits, tgt, 19)
+        rec["logits%d" % i] = npy(logits)
+        rec["target%d" % i] = npy(tgt)
+        rec["metrics%d" % i] = np.array([m[k] for k in keys], dtype=np.float64)
+    np.savez(os.path.join(OUT, "seg_metrics.npz"), **rec)
+    print("wrote seg_metrics")
+
+
 SELECTED = ("conv1.0.weight", "ResLayer2.0.shortcut.0.weight", "ResLayer4.1.left.3.weight", "Upsample.pwc.0.weight",
             "in_conv.0.weight", "down2.1.3.weight", "up1.up.weight", "up1.up.bias", "up4.conv.0.weight",
             "out_conv.0.weight", "out_conv.0.bias", "out_conv.2.weight", "out_conv.2.bias", "down4.1.1.weight")
@@ -236,6 +271,7 @@ def main():
     module_case("outconv_cls_128_100", lambda: cifar.OutConv(128, 100), [(2, 128, 4, 4)])
     shuffle_case(seg)
     loss_case()
+    metrics_case()
     seg_model_case("seg_newEUCB_c8", lambda: seg.UResNetNewEUCB(19, 3, 8), 19, (1, 3, 32, 64))
     seg_model_case("seg_uresnet_c8_bce", lambda: ice.UResNet(1, 3, 8), 1, (2, 3, 32, 32))
     seg_model_case("seg_noEUCB_c8", lambda: seg.UResNetNoEUCB(19, 3, 8), 19, (1, 3, 32, 48), steps=1)

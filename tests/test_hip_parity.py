@@ -579,6 +579,61 @@ def test_residual_gradient_in_dgrad_epilogue_is_bit_exact(pkg, cin, cout):
         assert torch.equal(a, b)
 
 
+METRIC_KEYS = ("precision", "recall", "accuracy", "f1", "iou", "dice")
+
+
+def test_confusion_matrix_and_metrics_match_reference(pkg):
+    """GPU confusion matrix == bincount of (target, argmax); metrics == the values recorded from the reference's
+    calculate_metrics (sklearn) to 1e-12, for fp32 and bf16 logits (bf16: against the argmax of the rounded logits)."""
+    rec = load_golden("seg_metrics")
+    for i in range(3):
+        lg, tg = torch.from_numpy(rec["logits%d" % i]), torch.from_numpy(rec["target%d" % i])
+        m = pkg.train.calculate_metrics(lg.to(DEV), tg.to(DEV), 19)
+        np.testing.assert_allclose([m[k] for k in METRIC_KEYS], rec["metrics%d" % i], rtol=0, atol=1e-12)
+        for dtype in (torch.float32, torch.bfloat16):
+            act = pkg.ops.as_activation(lg.to(DEV), dtype)
+            cm = pkg.ops.confusion_matrix(act, tg.to(DEV), 19)
+            pred = host(pkg, act).argmax(1).flatten()
+            keep = tg.flatten() != 255
+            want = torch.bincount(tg.flatten()[keep] * 19 + pred[keep], minlength=361).view(19, 19)
+            assert torch.equal(cm.cpu(), want)
+            pkg.ops.confusion_matrix(act, tg.to(DEV), 19, out=cm)          # accumulates
+            assert torch.equal(cm.cpu(), 2 * want)
+    # more classes than the LDS histogram holds, 2-D logits, out-of-range targets skipped
+    g = torch.Generator().manual_seed(2)
+    lg = torch.randn(5000, 40, generator=g)
+    tg = torch.randint(-1, 41, (5000,), generator=g)
+    cm = pkg.ops.confusion_matrix(lg.to(DEV), tg.to(DEV), 40, ignore_index=7)
+    keep = (tg >= 0) & (tg < 40) & (tg != 7)
+    want = torch.bincount(tg[keep] * 40 + lg.argmax(1)[keep], minlength=1600).view(40, 40)
+    assert torch.equal(cm.cpu(), want)
+
+
+def test_validate_matches_oracle(pkg, oracle):
+    """validate(): eval-mode forward, mean loss and mean per-batch metrics of two batches == the CPU restatement."""
+    pytest.importorskip("sklearn")
+    torch.manual_seed(0)
+    m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 8).set_compute_dtype(torch.float32).to(DEV)
+    ref = oracle.UResNetNewEUCB(19, 3, 8)
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for _ in range(2):
+        x = torch.randn(2, 3, 32, 64, generator=g)
+        t = torch.randint(0, 19, (2, 32, 64), generator=g)
+        t[torch.rand(t.shape, generator=g) < 0.1] = 255
+        batches.append((x, t))
+    loss, metrics = pkg.train.validate(m, batches, DEV, 19)
+    rloss, rmetrics = oracle.validate(ref, batches, "cpu", 19)
+    assert not m.training
+    assert abs(loss - rloss) < 1e-5 * abs(rloss)
+    # random-init logits are nearly flat: a pixel whose top two classes differ by float round-off may flip its argmax
+    for k in METRIC_KEYS:
+        assert abs(metrics[k] - rmetrics[k]) < 2e-3, k
+    with pytest.raises(ZeroDivisionError):
+        pkg.train.validate(m, [], DEV, 19)
+
+
 def test_seg_model_ragged_size_matches_oracle(pkg, oracle):
     """36 x 52 input: level 3 is 9 x 13, so that Up block pads (unfused path) while the others write the skip tensor
     and the transposed convolution straight into the concatenated tensor."""

@@ -80,6 +80,18 @@ def test_losses_and_masks(oracle):
     assert torch.equal(oracle.sigmoid_mask(torch.from_numpy(rec["sg_logits"])), torch.from_numpy(rec["sg_mask"]))
 
 
+METRIC_KEYS = ("precision", "recall", "accuracy", "f1", "iou", "dice")
+
+
+def test_seg_metrics_match_reference(oracle):
+    """calculate_metrics against values recorded from the reference's own function (absent labels, zero divisions)."""
+    pytest.importorskip("sklearn")
+    rec = load_golden("seg_metrics")
+    for i in range(3):
+        m = oracle.calculate_metrics(torch.from_numpy(rec["logits%d" % i]), torch.from_numpy(rec["target%d" % i]), 19)
+        np.testing.assert_allclose([m[k] for k in METRIC_KEYS], rec["metrics%d" % i], rtol=0, atol=1e-15)
+
+
 @pytest.mark.parametrize("name", sorted(SEG_MODEL_CASES))
 def test_seg_model_matches_reference(oracle, name):
     cls, args, classes = SEG_MODEL_CASES[name]

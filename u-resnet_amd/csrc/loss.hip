@@ -196,6 +196,73 @@ __global__ __launch_bounds__(NT) void sigmoid_mask_kernel(const T* __restrict__ 
     }
 }
 
+// Confusion matrix of argmax(logits) against the targets: cm[t][p] += 1 for every pixel whose target is a class
+// (ignore_index and out-of-range targets are skipped).  Workgroup-private counts in LDS (classes <= CM_LDS_CLASSES),
+// then one 64-bit integer atomic per non-zero cell: integer sums, so the result does not depend on the order.
+constexpr int CM_LDS_CLASSES = 32;
+template <typename T>
+__global__ __launch_bounds__(NT) void confusion_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                       long long rows, int classes, int ld, long long ignore_index,
+                                                       unsigned long long* __restrict__ cm) {
+    __shared__ unsigned int local[CM_LDS_CLASSES * CM_LDS_CLASSES];
+    const bool use_lds = classes <= CM_LDS_CLASSES;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < classes * classes; i += NT) local[i] = 0;
+        __syncthreads();
+    }
+    for (long long r = blockIdx.x * (long long)NT + threadIdx.x; r < rows; r += (long long)gridDim.x * NT) {
+        const long long t = target[r];
+        if (t == ignore_index || t < 0 || t >= classes) continue;
+        const T* row = logits + r * ld;
+        float m = ur_to_float(row[0]);
+        int best = 0;
+        for (int c = 1; c < classes; ++c) {
+            const float v = ur_to_float(row[c]);
+            if ((v > m) || (v != v && m == m)) { m = v; best = c; }        // same tie / NaN rule as argmax_kernel
+        }
+        if (use_lds) atomicAdd(&local[(int)t * classes + best], 1u);
+        else atomicAdd(&cm[(size_t)t * classes + best], 1ull);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < classes * classes; i += NT)
+            if (local[i]) atomicAdd(&cm[i], (unsigned long long)local[i]);
+    }
+}
+
+// Macro-averaged precision / recall / F1 / Jaccard and the accuracy of one confusion matrix, added to
+// acc[0..6] = (precision, recall, accuracy, f1, iou, count of matrices, loss sum: += *loss when given).  The average runs over the labels that occur
+// in the targets or in the predictions, a label with a zero denominator scores 0 (sklearn's average='macro',
+// zero_division=0 as called at train_UResNetAblitionStudy.py:82-89).  One wave, double arithmetic, fixed order.
+__global__ __launch_bounds__(64) void seg_metrics_kernel(const unsigned long long* __restrict__ cm, int classes,
+                                                         const float* __restrict__ loss, double* __restrict__ acc) {
+    double pr = 0.0, rc = 0.0, f1 = 0.0, io = 0.0, tp_all = 0.0, total = 0.0, labels = 0.0;
+    for (int k = threadIdx.x; k < classes; k += 64) {
+        double tp = (double)cm[(size_t)k * classes + k], row = 0.0, col = 0.0;
+        for (int j = 0; j < classes; ++j) { row += (double)cm[(size_t)k * classes + j]; col += (double)cm[(size_t)j * classes + k]; }
+        const double fn = row - tp, fp = col - tp;
+        if (row + col > 0.0) {
+            labels += 1.0;
+            pr += (tp + fp) > 0.0 ? tp / (tp + fp) : 0.0;
+            rc += (tp + fn) > 0.0 ? tp / (tp + fn) : 0.0;
+            f1 += (2.0 * tp + fp + fn) > 0.0 ? 2.0 * tp / (2.0 * tp + fp + fn) : 0.0;
+            io += (tp + fp + fn) > 0.0 ? tp / (tp + fp + fn) : 0.0;
+        }
+        tp_all += tp; total += row;
+    }
+    __shared__ double red[7][64];
+    red[0][threadIdx.x] = pr; red[1][threadIdx.x] = rc; red[2][threadIdx.x] = f1; red[3][threadIdx.x] = io;
+    red[4][threadIdx.x] = tp_all; red[5][threadIdx.x] = total; red[6][threadIdx.x] = labels;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double s[7];
+    for (int q = 0; q < 7; ++q) { s[q] = 0.0; for (int l = 0; l < 64; ++l) s[q] += red[q][l]; }
+    const double nl = s[6] > 0.0 ? s[6] : 1.0;
+    acc[0] += s[0] / nl; acc[1] += s[1] / nl; acc[2] += s[5] > 0.0 ? s[4] / s[5] : 0.0;
+    acc[3] += s[2] / nl; acc[4] += s[3] / nl; acc[5] += 1.0;
+    if (loss) acc[6] += (double)loss[0];
+}
+
 int loss_blocks(long long n) { return ur_grid_1d(n, NT, 1024); }
 
 }  // namespace
@@ -269,6 +336,20 @@ int ur_argmax_channels(const void* logits, int dtype, long long rows, int classe
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((argmax_kernel<T>), dim3(ur_grid_1d(rows, NT)), dim3(NT), 0, (hipStream_t)s,
                                                 (const T*)logits, rows, classes, ld, out));
     return ur_check_launch("argmax");
+}
+
+int ur_confusion_matrix(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
+                        long long ignore_index, unsigned long long* cm, ur_stream_t s) {
+    UR_REQUIRE(logits && target && cm && rows > 0 && classes > 0 && ld >= classes, "confusion_matrix: bad arguments");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((confusion_kernel<T>), dim3(ur_grid_1d(rows, NT * 4, 2048)), dim3(NT), 0,
+                                                (hipStream_t)s, (const T*)logits, target, rows, classes, ld, ignore_index, cm));
+    return ur_check_launch("confusion_matrix");
+}
+
+int ur_seg_metrics_accumulate(const unsigned long long* cm, int classes, const float* loss, double* acc7, ur_stream_t s) {
+    UR_REQUIRE(cm && acc7 && classes > 0, "seg_metrics: bad arguments");
+    hipLaunchKernelGGL(seg_metrics_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, cm, classes, loss, acc7);
+    return ur_check_launch("seg_metrics");
 }
 
 int ur_sigmoid_mask(const void* logits, int dtype, long long count, uint8_t* out, ur_stream_t s) {

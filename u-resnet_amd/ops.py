@@ -1030,6 +1030,41 @@ def bce_with_logits(logits, target):
     return _BCEWithLogits.apply(logits, target)
 
 
+def confusion_matrix(logits, targets, num_classes, ignore_index=255, out=None):
+    """int64 [num_classes, num_classes] counts cm[target][argmax(logits)] over the pixels whose target is a class
+    (argmax and histogram in one pass; `out` accumulates).  logits: [N,C,H,W] activation or [rows, C]."""
+    _require_gpu(logits)
+    if logits.dim() == 4:
+        n, c, h, w = logits.shape
+        if not _is_nhwc_dense(logits):
+            logits = to_nhwc_raw(logits.contiguous(), logits.dtype)
+        rows = n * h * w
+    else:
+        rows, c = logits.shape
+        logits = logits.contiguous()
+    if c != num_classes:
+        raise RuntimeError("confusion_matrix: logits have %d channels, num_classes is %d" % (c, num_classes))
+    if targets.dtype != torch.int64:
+        targets = targets.long()
+    targets = targets.contiguous()
+    if targets.numel() != rows or targets.device != logits.device:
+        raise RuntimeError("confusion_matrix: targets must hold one class per pixel on the logits' device")
+    cm = torch.zeros((c, c), dtype=torch.int64, device=logits.device) if out is None else out
+    call("ur_confusion_matrix", logits.data_ptr(), _dt(logits), targets.data_ptr(), rows, c, c, ignore_index, cm.data_ptr(),
+         _stream())
+    return cm
+
+
+def seg_metrics_accumulate(cm, acc, loss=None):
+    """acc (float64[7], device) += (precision, recall, accuracy, f1, iou, 1, loss) of the confusion matrix cm."""
+    if acc.dtype != torch.float64 or acc.numel() != 7 or cm.dtype != torch.int64 or cm.dim() != 2 or not cm.is_contiguous():
+        raise RuntimeError("seg_metrics_accumulate: cm must be int64 [C,C], acc float64[7]")
+    if loss is not None and (loss.dtype != torch.float32 or loss.numel() != 1):
+        raise RuntimeError("seg_metrics_accumulate: loss must be a float32 scalar tensor")
+    call("ur_seg_metrics_accumulate", cm.data_ptr(), cm.shape[0], _p(loss), acc.data_ptr(), _stream())
+    return acc
+
+
 def argmax_channels(logits):
     """preds.argmax(1) for NHWC logits -> int64 [N,H,W] (first maximum wins)."""
     _require_gpu(logits)

@@ -4,6 +4,7 @@
   Adam / SGD        optim.Adam(lr=1e-4) (same file :203), optim.SGD(lr=0.01) (Classification/CNN-CIFAR10.py:130)
   train steps       train_UResNetAblitionStudy.py:115-122, CNN-CIFAR10.py:145-149, Ice-Seg/TrainingCode.py:107-115
   masks             preds.argmax(1) (train_UResNetAblitionStudy.py:73), sigmoid(outputs) > 0.5 (TrainingCode.py:132)
+  metrics           calculate_metrics / validate (train_UResNetAblitionStudy.py:70-100, 128-164)
 """
 import torch
 
@@ -35,6 +36,52 @@ def argmax_mask(outputs):
 
 def sigmoid_mask(outputs):
     return ops.sigmoid_mask(outputs)
+
+
+_METRIC_KEYS = ('precision', 'recall', 'accuracy', 'f1', 'iou')
+
+
+def _metrics_dict(acc):
+    v = acc.cpu().tolist()                       # the only host synchronisation
+    n = v[5] if v[5] > 0 else 1.0
+    m = {k: v[i] / n for i, k in enumerate(_METRIC_KEYS)}
+    m['dice'] = m['f1']                          # the reference reports the F1 score again as `dice`
+    return m, v[6] / n
+
+
+def calculate_metrics(preds, targets, num_classes):
+    """train_UResNetAblitionStudy.py:70-100: macro precision / recall / F1 / IoU and accuracy of argmax(preds) on the
+    pixels whose target is not 255 -- from a confusion matrix built on the GPU instead of sklearn on flattened copies."""
+    if isinstance(preds, list):
+        preds = preds[0]
+    cm = ops.confusion_matrix(preds, targets, num_classes, ignore_index=255)
+    acc = torch.zeros(7, dtype=torch.float64, device=cm.device)
+    ops.seg_metrics_accumulate(cm, acc)
+    return _metrics_dict(acc)[0]
+
+
+def validate(model, data_loader, device, num_classes):
+    """train_UResNetAblitionStudy.py:128-164: eval-mode forward, mean loss and mean per-batch metrics.  Loss and metrics
+    accumulate on the device; the host reads them once after the last batch."""
+    model.eval()
+    acc = None
+    with torch.no_grad():
+        for images, targets in data_loader:
+            images, targets = images.to(device), targets.to(device)
+            outputs = model(images)
+            loss = compute_loss(outputs, targets)
+            if isinstance(outputs, list):
+                outputs = outputs[0]
+            if acc is None:
+                acc = torch.zeros(7, dtype=torch.float64, device=outputs.device)
+                cm = torch.zeros((num_classes, num_classes), dtype=torch.int64, device=outputs.device)
+            cm.zero_()
+            ops.confusion_matrix(outputs, targets, num_classes, ignore_index=255, out=cm)
+            ops.seg_metrics_accumulate(cm, acc, loss.detach().float().reshape(1))
+    if acc is None:
+        raise ZeroDivisionError("validate: empty data loader")
+    metrics, mean_loss = _metrics_dict(acc)
+    return mean_loss, metrics
 
 
 class _MultiTensorOptimizer(torch.optim.Optimizer):
