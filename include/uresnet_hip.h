@@ -90,6 +90,11 @@ int ur_conv3x3_tile_fwd(const void* x, const void* w_packed, void* y, float* sta
                         ur_stream_t s);
 int ur_conv3x3_tile_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const ur_conv_desc* d,
                           ur_stream_t s);
+/* Inference with fixed BatchNorm statistics folded into the convolution's epilogue (model.eval(), S/C:95-99,141-158):
+ * y = act(conv(x) * scale[c] + shift[c] (+ residual)), scale = gamma * invstd, shift = beta - mean * scale
+ * (ur_bn_eval_affine).  No intermediate tensor, no BatchNorm pass.  relu != 0 clamps at zero; residual may be NULL. */
+int ur_conv3x3_tile_fwd_affine(const void* x, const void* w_packed, void* y, const float* scale, const float* shift, int relu,
+                               const void* residual, int res_ld, const ur_conv_desc* d, ur_stream_t s);
 /* dx = round(conv_backward_input(dy)) + addend: the input of a residual block (S/C:156-159) has a second gradient
  * from the shortcut; it is added in the epilogue (same rounding as a separate add of the two bf16 tensors).
  * add_ld = channel pitch of addend in elements (0 or cin: dense). */
@@ -145,6 +150,10 @@ int ur_bn_finalize(float* partial, int nparts, long long count, int c, float eps
 /* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
 int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int c, float eps, float* mean,
                        float* invstd, ur_stream_t s);
+/* eval mode folded to one multiply-add per channel: scale = gamma * rsqrt(running_var + eps),
+ * shift = beta - running_mean * scale */
+int ur_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma, const float* beta, int c,
+                      float eps, float* scale, float* shift, ur_stream_t s);
 /* z = act((y-mean)*invstd*gamma + beta (+ residual));  act: 0 none, 1 relu.  z_ld = channel pitch of z in
  * elements (0 or c: dense); a larger pitch writes into a channel window of a wider NHWC tensor (the skip half
  * of a torch.cat, S/C:119-124) */

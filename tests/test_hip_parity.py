@@ -634,6 +634,39 @@ def test_validate_matches_oracle(pkg, oracle):
         pkg.train.validate(m, [], DEV, 19)
 
 
+def test_inference_folds_batchnorm_into_the_convolution(pkg, oracle):
+    """eval() under no_grad: the tile kernel applies BatchNorm's fixed statistics (and residual, ReLU) in its epilogue.
+    bf16 tolerance 1e-2 against the fp32 oracle and against the unfused kernels; fp32 models take the unfused path."""
+    torch.manual_seed(3)
+    m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 64).to(DEV)
+    ref = oracle.UResNetNewEUCB(19, 3, 64)
+    with torch.no_grad():                          # non-trivial statistics
+        for mod in m.modules():
+            if isinstance(mod, pkg.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.7, 1.3); mod.bias.uniform_(-0.2, 0.2)
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    m.eval(); ref.eval()
+    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = ref(x)
+        m.set_compute_dtype(torch.bfloat16)
+        timings = pkg.ops.kernel_timings = []
+        fused = host(pkg, m(x.to(DEV)))
+        pkg.ops.kernel_timings = None
+        pkg.nn.fuse_eval_bn = False
+        try:
+            unfused = host(pkg, m(x.to(DEV)))
+        finally:
+            pkg.nn.fuse_eval_bn = True
+        m.set_compute_dtype(torch.float32)
+        f32 = host(pkg, m(x.to(DEV)))
+    assert sum(1 for t in timings if t[0] == "tile_fwd") >= 25       # the fused kernel really ran
+    assert rel_l2(f32, want) < 1e-4
+    assert rel_l2(fused, want) < 2e-2 and rel_l2(unfused, want) < 2e-2
+    assert rel_l2(fused, unfused) < 1e-2
+
+
 def test_seg_model_ragged_size_matches_oracle(pkg, oracle):
     """36 x 52 input: level 3 is 9 x 13, so that Up block pads (unfused path) while the others write the skip tensor
     and the transposed convolution straight into the concatenated tensor."""

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ur_conv3x3_tile_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad_add": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _vp]),
+    "ur_conv3x3_tile_fwd_affine": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _dp, _vp]),
     "ur_wgrad3x3_tile_supported": (_i, [_dp]),
     "ur_wgrad3x3_tile_workspace": (_sz, [_dp]),
     "ur_wgrad3x3_tile": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "ur_bn_stats": (_i, [_vp, _i, _ll, _i, _vp, _vp]),
     "ur_bn_finalize": (_i, [_vp, _i, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ur_bn_eval_prepare": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "ur_bn_eval_affine": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "ur_bn_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _i, _vp]),
     "ur_bn_act_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _i, _vp, _vp]),
     "ur_bn_bwd_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),

@@ -213,6 +213,16 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts
     }
 }
 
+__global__ void bn_eval_affine_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, int C, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float k = gamma[c] * (1.f / sqrtf(rvar[c] + eps));
+    scale[c] = k;
+    shift[c] = beta[c] - rmean[c] * k;
+}
+
 __global__ void bn_eval_prepare_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C,
                                        float eps, float* __restrict__ mean, float* __restrict__ invstd) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,6 +654,14 @@ int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int 
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, running_mean,
                        running_var, c, eps, mean, invstd);
     return ur_check_launch("bn_eval_prepare");
+}
+
+int ur_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma, const float* beta, int c,
+                      float eps, float* scale, float* shift, ur_stream_t s) {
+    UR_REQUIRE(running_mean && running_var && gamma && beta && scale && shift && c > 0, "bn_eval_affine: bad arguments");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, running_mean, running_var,
+                       gamma, beta, c, eps, scale, shift);
+    return ur_check_launch("bn_eval_affine");
 }
 
 int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,

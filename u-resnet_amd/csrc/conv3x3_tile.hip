@@ -54,8 +54,11 @@ struct TileParams {
     const bf16_t* wpk;    // [Cout/64][Cin/16][9][2][64][8]
     bf16_t* y;            // [N][H][W][ld_out]
     float* stats;         // [tiles][Cout][2] or null
-    const bf16_t* addend; // [N][H][W][ld_add] or null: added to the rounded result (a second gradient of the same tensor)
-    int ld_add;
+    const bf16_t* addend; // [N][H][W][ld_add] or null: added to the rounded result (a second gradient of the same tensor,
+    int ld_add;           //   or the residual of an inference-mode block)
+    const float* scale;   // [Cout] or null: result = acc * scale + shift (BatchNorm with fixed statistics, folded)
+    const float* shift;
+    int relu;             // clamp at zero after the affine map and the addend
     int N, H, W, Cin, Cout;
     int ld_in, ld_out;
     int tiles_x, tiles_y, tiles;     // spatial tiles per image row / column / total (N * ty * tx)
@@ -306,6 +309,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
     unsigned char* ostage = lds + wave * (R * TW * OUT_PITCH);
     float* red = reinterpret_cast<float*>(lds + G::OUT_BYTES);
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float aff_sc[2] = {1.f, 1.f}, aff_sh[2] = {0.f, 0.f};
+    if (p.scale) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { aff_sc[b] = p.scale[nb * BN + b * 32 + lx]; aff_sh[b] = p.shift[nb * BN + b * 32 + lx]; }
+    }
 #pragma unroll
     for (int a = 0; a < R; ++a) {
         const int oy = ty0 + wave * R + a;
@@ -314,7 +322,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float v = acc[a][b][r];
+                float v = acc[a][b][r];
+                if (p.scale) {
+                    v = v * aff_sc[b] + aff_sh[b];
+                    if (p.relu && !p.addend) v = fmaxf(v, 0.f);
+                }
                 *reinterpret_cast<bf16_t*>(ostage + (a * TW + px) * OUT_PITCH + (b * 32 + lx) * 2) = (bf16_t)v;
                 if (oy < p.H && tx0 + px < p.W) { s1[b] += v; s2[b] += v * v; }
             }
@@ -333,7 +345,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
             if (p.addend) {
                 const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (bf16_t)((float)v[k] + (float)a[k]);
+                for (int k = 0; k < 8; ++k) {
+                    float t = (float)v[k] + (float)a[k];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    v[k] = (bf16_t)t;
+                }
             }
             *reinterpret_cast<bf16x8_t*>(p.y + pix * p.ld_out + nb * BN + piece * 8) = v;
         }
@@ -435,12 +451,14 @@ int pick_rows(const ur_conv_desc* d, bool dgrad) {
 }
 
 int launch(const void* src, const void* wpk, void* dst, float* stats, const ur_conv_desc* d, bool dgrad, hipStream_t st,
-           const void* addend = nullptr, int add_ld = 0) {
+           const void* addend = nullptr, int add_ld = 0, const float* scale = nullptr, const float* shift = nullptr,
+           int relu = 0) {
     const int R = pick_rows(d, dgrad);
     const int TH = 4 * R;
     TileParams p{};
     p.x = (const bf16_t*)src; p.wpk = (const bf16_t*)wpk; p.y = (bf16_t*)dst; p.stats = stats;
     p.addend = (const bf16_t*)addend; p.ld_add = add_ld;
+    p.scale = scale; p.shift = shift; p.relu = relu;
     p.N = d->n; p.H = d->h; p.W = d->w;
     p.Cin = dgrad ? d->cout : d->cin; p.Cout = dgrad ? d->cin : d->cout;
     p.ld_in = dgrad ? d->out_ld : d->in_ld; p.ld_out = dgrad ? d->in_ld : d->out_ld;
@@ -500,6 +518,20 @@ int ur_conv3x3_tile_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, 
     if (int e = check(d, true)) return e;
     UR_REQUIRE(dy && w_packed_dgrad && dx, "conv3x3_tile_dgrad: null pointer");
     return launch(dy, w_packed_dgrad, dx, nullptr, d, true, (hipStream_t)s);
+}
+
+int ur_conv3x3_tile_fwd_affine(const void* x, const void* w_packed, void* y, const float* scale, const float* shift, int relu,
+                               const void* residual, int res_ld, const ur_conv_desc* d, ur_stream_t s) {
+    if (int e = check(d, false)) return e;
+    UR_REQUIRE(x && w_packed && y && scale && shift, "conv3x3_tile_fwd_affine: null pointer");
+    if (residual) {
+        if (res_ld == 0) res_ld = d->cout;
+        UR_REQUIRE(res_ld >= d->cout && res_ld % 8 == 0 && ((uintptr_t)residual % 16) == 0,
+                   "conv3x3_tile_fwd_affine: residual pitch %d must be a multiple of 8 >= %d and the pointer 16-byte aligned",
+                   res_ld, d->cout);
+        UR_REQUIRE((long long)d->n * d->h * d->w * res_ld < (1LL << 31), "conv3x3_tile_fwd_affine: residual exceeds 2^31 elements");
+    }
+    return launch(x, w_packed, y, nullptr, d, false, (hipStream_t)s, residual, res_ld, scale, shift, relu != 0);
 }
 
 int ur_conv3x3_tile_dgrad_add(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,

@@ -174,7 +174,17 @@ def has_hooks(*mods):
     return False
 
 
+fuse_eval_bn = True          # False: inference runs convolution and BatchNorm as separate kernels (A/B comparisons)
+
+
 def conv_bn_act(x, conv, bn, act=_lib.ACT_RELU, residual=None, out=None):
-    """conv -> BatchNorm (training statistics taken from the conv kernel's epilogue) -> (+residual) -> act."""
+    """conv -> BatchNorm (training statistics taken from the conv kernel's epilogue) -> (+residual) -> act.
+    Inference (bn in eval mode under torch.no_grad()): BatchNorm is folded into the convolution's epilogue."""
+    if (fuse_eval_bn and not bn.training and not torch.is_grad_enabled() and isinstance(conv, Conv2d) and conv.groups == 1
+            and conv.bias is None and (conv._k, conv._s, conv._p) == (3, 1, 1)):
+        xa = ops.as_activation(x, act_dtype(x), allow_window=True)
+        z = ops.conv3x3_bn_eval(xa, conv.weight, conv._packs, bn, act, residual, out)
+        if z is not None:
+            return z
     y, stats = conv.raw(x, want_stats=bn.training)
     return ops.bn_act(y, bn, residual=residual, stats=stats, act=act, out=out)

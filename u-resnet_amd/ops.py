@@ -463,6 +463,46 @@ def conv2d(x, weight, bias, packs, stride=1, pad=0, want_stats=False, out=None, 
     return (y, stats, alias) if want_alias else (y, stats)
 
 
+def conv3x3_bn_eval(x, weight, packs, bn, act, residual=None, out=None):
+    """Inference only (no autograd): act(BN_eval(conv3x3(x)) (+ residual)) in ONE kernel -- the fixed statistics are
+    folded to a per-channel multiply-add in the tile kernel's epilogue, so neither the raw convolution output nor a
+    BatchNorm pass touches memory.  Returns None when the layer is not one the tile kernel takes (the caller then runs
+    convolution and BatchNorm separately)."""
+    if (not use_tile_kernel or torch.is_grad_enabled() or x.dtype != torch.bfloat16 or not x.is_cuda or x.dim() != 4
+            or act not in (_lib.ACT_NONE, _lib.ACT_RELU) or bn.running_mean is None or tuple(weight.shape[2:]) != (3, 3)):
+        return None
+    cout, cin = weight.shape[0], weight.shape[1]
+    n, cx, h, w = x.shape
+    in_ld = _channel_pitch(x)
+    if cx != cin or not in_ld:
+        return None
+    d = _desc(x.shape, cout, 3, 3, 1, 1, x.dtype)
+    d.in_ld = in_ld
+    res_ld = 0
+    if residual is not None:
+        res_ld = _channel_pitch(residual) if (residual.dtype == x.dtype and residual.is_cuda) else 0
+        if tuple(residual.shape) != (n, cout, h, w) or not res_ld or res_ld % 8 or residual.data_ptr() % 16:
+            return None
+    if out is None:
+        z = empty_nhwc(n, cout, h, w, x.dtype, x.device)
+    else:
+        z = out
+        d.out_ld = _channel_pitch(z)
+        if tuple(z.shape) != (n, cout, h, w) or z.dtype != x.dtype or not d.out_ld:
+            raise RuntimeError("conv3x3_bn_eval: `out` must be a channel window with the output's shape and dtype")
+    if not query("ur_conv3x3_tile_supported", C.byref(d), 0):
+        return None
+    scale = torch.empty(cout, dtype=torch.float32, device=x.device)
+    shift = torch.empty(cout, dtype=torch.float32, device=x.device)
+    call("ur_bn_eval_affine", bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+         cout, bn.eps, scale.data_ptr(), shift.data_ptr(), _stream())
+    wp = packs.get_tile(weight, d, False)
+    with _Timed("tile_fwd", _conv_flops(d), d):
+        call("ur_conv3x3_tile_fwd_affine", x.data_ptr(), wp.data_ptr(), z.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+             int(act == _lib.ACT_RELU), _p(residual), res_ld, C.byref(d), _stream())
+    return z
+
+
 class _ConvT2x2(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, packs):
