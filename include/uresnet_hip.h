@@ -219,6 +219,15 @@ int ur_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, in
 int ur_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int h, int w,
                     ur_stream_t s);
 
+/* input packing, the step before the hot path (Segmentation/Cityscapes/DataInstance/Cityscapes.py:191-194,
+ * 220-223, 238, 256): uint8 HWC pixels -> NHWC activation, out[ch] = (px[ch] - sub[ch]) * mul[ch] for ch < c and 0 for
+ * c <= ch < out_c (sub / mul: HOST arrays of c <= 4 floats; Normalize(mean, std) is sub = 255 mean, mul = 1/(255 std);
+ * divide != 0 computes (px - sub) / mul instead, correctly rounded: image / 255.0 is sub = 0, mul = 255);
+ * label ids -> int64 classes through a HOST table of 256 bytes. */
+int ur_pack_image_u8(const uint8_t* img, void* out, int dtype, long long pixels, int c, int out_c, const float* sub,
+                     const float* mul, int divide, ur_stream_t s);
+int ur_remap_labels_u8(const uint8_t* ids, int64_t* out, long long count, const uint8_t* lut256, ur_stream_t s);
+
 /* ---------------------------------------------------------------- losses and masks
  * CrossEntropyLoss(ignore_index) (train_UResNetAblitionStudy.py:66-67, CNN-CIFAR10.py:129),
  * BCEWithLogitsLoss (Ice-Seg/TrainingCode.py:97), argmax(1) (train_UResNetAblitionStudy.py:73),

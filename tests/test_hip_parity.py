@@ -579,6 +579,34 @@ def test_residual_gradient_in_dgrad_epilogue_is_bit_exact(pkg, cin, cout):
         assert torch.equal(a, b)
 
 
+def test_input_packing_matches_the_dataset_class(pkg, oracle):
+    """uint8 batch on the GPU -> normalised NHWC activation and remapped int64 targets == the per-sample CPU steps of the
+    reference's dataset class (labels and fp32 pixels bit-exact, bf16 = the rounded fp32 value, padding channels zero)."""
+    g = torch.Generator().manual_seed(6)
+    img = torch.randint(0, 256, (2, 20, 36, 3), generator=g, dtype=torch.uint8)
+    ids = torch.randint(0, 40, (2, 20, 36), generator=g, dtype=torch.uint8)
+    ids[0, 0, :5] = torch.tensor([255, 0, 33, 7, 34], dtype=torch.uint8)
+    want_t = torch.stack([oracle.cityscapes_remap(ids[i].numpy()) for i in range(2)])
+    got_t = pkg.data.remap_labels(ids.to(DEV))
+    assert got_t.dtype == torch.int64 and torch.equal(got_t.cpu(), want_t)
+    assert set(want_t.unique().tolist()) <= set(range(19)) | {255}
+    for mean, std in (((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)), (None, None)):
+        want = torch.stack([oracle.normalize_to_tensor(img[i].numpy(), mean, std) for i in range(2)])
+        x = pkg.data.pack_images(img.to(DEV), torch.float32, mean, std)
+        assert tuple(x.shape) == (2, 3, 20, 36) and torch.equal(host(pkg, x), want)
+        xb = pkg.data.pack_images(img.to(DEV), torch.bfloat16, mean, std, pad_to=8)
+        assert tuple(xb.shape) == (2, 8, 20, 36)
+        hb = host(pkg, xb)
+        assert torch.equal(hb[:, :3], want.to(torch.bfloat16).float()) and bool((hb[:, 3:] == 0).all())
+    # the packed batch feeds the model like the loader's NCHW fp32 batch does
+    torch.manual_seed(0)
+    m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 8).set_compute_dtype(torch.float32).to(DEV).eval()
+    x = pkg.data.pack_images(img[:, :16, :32].contiguous().to(DEV), torch.float32)
+    ref_x = torch.stack([oracle.normalize_to_tensor(img[i, :16, :32].numpy()) for i in range(2)]).to(DEV)
+    with torch.no_grad():
+        assert torch.equal(m(x), m(ref_x))
+
+
 METRIC_KEYS = ("precision", "recall", "accuracy", "f1", "iou", "dice")
 
 

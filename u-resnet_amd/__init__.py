@@ -12,7 +12,7 @@ Layout
 The directory name contains a hyphen; import it as `uresnet_amd` (the alias module at the
 repository root) or with importlib.import_module("u-resnet_amd").
 """
-from . import _lib, ops, nn, train, ddp            # noqa: F401
+from . import _lib, ops, nn, train, ddp, data      # noqa: F401
 from .modules import U_ResNet, U_ResNet_CIFAR, U_ResNet_MiniImageNet   # noqa: F401
 from .nn import set_default_dtype, get_default_dtype   # noqa: F401
 

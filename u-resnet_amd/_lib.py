@@ -81,6 +81,8 @@ SIGNATURES = {
     "ur_act_bwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _f, _vp]),
     "ur_add_inplace": (_i, [_vp, _vp, _i, _ll, _vp]),
     "ur_nchw_to_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ur_pack_image_u8": (_i, [_vp, _vp, _i, _ll, _i, _i, _vp, _vp, _i, _vp]),
+    "ur_remap_labels_u8": (_i, [_vp, _vp, _ll, _vp, _vp]),
     "ur_nhwc_to_nchw": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ur_loss_workspace": (_sz, [_ll]),
     "ur_ce_fwd": (_i, [_vp, _i, _vp, _ll, _i, _i, _ll, _vp, _vp, _vp, _sz, _vp]),

@@ -332,6 +332,38 @@ bool al(const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; }
 #define UR_REQUIRE_32BIT(total, what) UR_REQUIRE((long long)(total) < (1LL << 31), what ": more than 2^31 elements")
 int esize(int dtype) { return dtype == UR_BF16 ? 2 : 4; }
 
+// ------------------------------------------------------------------ input packing (the step before the hot path)
+// HWC uint8 image -> NHWC activation: out[c] = (float(px[c]) - sub[c]) * mul[c] for c < C, 0 for C <= c < OC
+// (two separately rounded fp32 operations: albumentations' Normalize computes img -= mean*255; img *= 1/(std*255));
+// with `divide` the second operation is a correctly rounded division by mul[c] (image / 255.0).
+struct PackConsts { float sub[4], mul[4]; int divide; };
+template <typename T>
+__global__ __launch_bounds__(NT) void pack_image_kernel(const uint8_t* __restrict__ img, T* __restrict__ out, long long pixels,
+                                                        int C, int OC, PackConsts k) {
+    for (long long p = blockIdx.x * (long long)NT + threadIdx.x; p < pixels; p += (long long)gridDim.x * NT) {
+        const uint8_t* px = img + p * C;
+        T* o = out + p * OC;
+        for (int c = 0; c < OC; ++c) {
+            float v = 0.f;
+            if (c < C) {
+                const float d = __fsub_rn((float)px[c], k.sub[c]);
+                v = k.divide ? __fdiv_rn(d, k.mul[c]) : __fmul_rn(d, k.mul[c]);
+            }
+            o[c] = ur_from_float<T>(v);
+        }
+    }
+}
+
+// label ids -> training classes through a 256-entry table (Cityscapes: 34 ids -> 19 classes, everything else 255)
+struct LabelLut { uint8_t v[256]; };
+__global__ __launch_bounds__(NT) void remap_labels_kernel(const uint8_t* __restrict__ ids, int64_t* __restrict__ out,
+                                                          long long count, LabelLut lut) {
+    __shared__ uint8_t tab[256];
+    tab[threadIdx.x] = lut.v[threadIdx.x];
+    __syncthreads();
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < count; i += (long long)gridDim.x * NT) out[i] = tab[ids[i]];
+}
+
 }  // namespace
 
 #define SPATIAL_LAUNCH(kernel, total, ...)                                                                     \
@@ -461,6 +493,26 @@ int ur_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, in
 int ur_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int h, int w, ur_stream_t s) {
     UR_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "nhwc_to_nchw: bad arguments");
     return transpose_dispatch(src, src_dtype, dst, dst_dtype, n, h * w, c, (hipStream_t)s);
+}
+
+int ur_pack_image_u8(const uint8_t* img, void* out, int dtype, long long pixels, int c, int out_c, const float* sub,
+                     const float* mul, int divide, ur_stream_t s) {
+    UR_REQUIRE(img && out && sub && mul && pixels > 0 && c > 0 && c <= 4 && out_c >= c, "pack_image_u8: bad arguments");
+    PackConsts k{};
+    k.divide = divide != 0;
+    for (int i = 0; i < c; ++i) { k.sub[i] = sub[i]; k.mul[i] = mul[i]; }
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_image_kernel<T>), dim3(ur_grid_1d(pixels, NT)), dim3(NT), 0, (hipStream_t)s,
+                                                img, (T*)out, pixels, c, out_c, k));
+    return ur_check_launch("pack_image_u8");
+}
+
+int ur_remap_labels_u8(const uint8_t* ids, int64_t* out, long long count, const uint8_t* lut256, ur_stream_t s) {
+    UR_REQUIRE(ids && out && lut256 && count > 0, "remap_labels_u8: bad arguments");
+    static_assert(NT == 256, "the table is loaded one entry per thread");
+    LabelLut lut;
+    for (int i = 0; i < 256; ++i) lut.v[i] = lut256[i];
+    hipLaunchKernelGGL(remap_labels_kernel, dim3(ur_grid_1d(count, NT)), dim3(NT), 0, (hipStream_t)s, ids, out, count, lut);
+    return ur_check_launch("remap_labels_u8");
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
   train steps       train_UResNetAblitionStudy.py:115-122, CNN-CIFAR10.py:145-149, Ice-Seg/TrainingCode.py:107-115
   masks             preds.argmax(1) (train_UResNetAblitionStudy.py:73), sigmoid(outputs) > 0.5 (TrainingCode.py:132)
   metrics           calculate_metrics / validate (train_UResNetAblitionStudy.py:70-100, 128-164)
+  checkpoints       the dict written at train_UResNetAblitionStudy.py:244-252 (save_checkpoint / load_checkpoint)
 """
 import torch
 
@@ -84,6 +85,30 @@ def validate(model, data_loader, device, num_classes):
     return mean_loss, metrics
 
 
+def save_checkpoint(path, model, optimizer, epoch, val_loss, metrics):
+    """The reference's best-model file (train_UResNetAblitionStudy.py:244-252): same keys, `module.`-free parameter
+    names, CPU tensors, torch.optim-compatible optimiser state."""
+    inner = getattr(model, 'module', model)
+    torch.save({'epoch': epoch,
+                'model_state_dict': {k: v.detach().cpu() for k, v in inner.state_dict().items()},
+                'optimizer_state_dict': optimizer.state_dict(),
+                'val_loss': val_loss,
+                'metrics': metrics}, path)
+
+
+def load_checkpoint(path, model, optimizer=None, map_location='cpu'):
+    """Load a checkpoint written by the reference's loop or by save_checkpoint (or a bare state_dict).  The file is read
+    with weights_only=True (tensors and plain containers only, nothing in it is executed); a `module.` prefix left by
+    nn.DataParallel is stripped.  Returns the checkpoint dict without the two state dicts."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    state = ckpt.get('model_state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
+    state = {(k[7:] if k.startswith('module.') else k): v for k, v in state.items()}
+    getattr(model, 'module', model).load_state_dict(state, strict=True)
+    if optimizer is not None and isinstance(ckpt, dict) and 'optimizer_state_dict' in ckpt:
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+    return {k: v for k, v in ckpt.items() if k not in ('model_state_dict', 'optimizer_state_dict')} if 'model_state_dict' in ckpt else {}
+
+
 class _MultiTensorOptimizer(torch.optim.Optimizer):
     """One kernel launch per step over every parameter that has a gradient (fp32 master weights)."""
     _slots = ()
@@ -116,10 +141,34 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
 
 
 class Adam(_MultiTensorOptimizer):
-    """torch.optim.Adam semantics (no amsgrad): exp_avg / exp_avg_sq state, bias correction, eps outside sqrt."""
+    """torch.optim.Adam semantics (no amsgrad): exp_avg / exp_avg_sq state, bias correction, eps outside sqrt.
+    state_dict() / load_state_dict() use torch.optim.Adam's layout (`step` as a float32 scalar tensor), so optimiser
+    states move between the two in either direction; internally the step count is a Python int."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['state'] = {k: {**v, 'step': torch.tensor(float(v['step']))} if 'step' in v else v for k, v in sd['state'].items()}
+        for g in sd['param_groups']:                 # torch.optim.Adam's remaining group keys, at their defaults
+            for k, v in (('amsgrad', False), ('maximize', False), ('foreach', None), ('capturable', False),
+                         ('differentiable', False), ('fused', None), ('decoupled_weight_decay', False)):
+                g.setdefault(k, v)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        for g in state_dict['param_groups']:
+            if g.get('amsgrad') or g.get('maximize'):
+                raise NotImplementedError("Adam: amsgrad / maximize states cannot be loaded")
+        keep = set(self.defaults) | {'params'}
+        slim = {'state': state_dict['state'],
+                'param_groups': [{k: v for k, v in g.items() if k in keep} for g in state_dict['param_groups']]}
+        super().load_state_dict(slim)
+        for st in self.state.values():
+            if 'step' in st and torch.is_tensor(st['step']):
+                st['step'] = int(round(float(st['step'])))
+        self._table_key = None
 
     @torch.no_grad()
     def step(self, closure=None):
