@@ -101,7 +101,8 @@ int ur_conv3x3_tile_fwd_affine(const void* x, const void* w_packed, void* y, con
 int ur_conv3x3_tile_dgrad_add(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
                               const ur_conv_desc* d, ur_stream_t s);
 
-/* backward-weight counterpart (same contract as ur_conv2d_wgrad; needs 64 | cin and 64 | cout) */
+/* backward-weight counterpart (same contract as ur_conv2d_wgrad; needs 32 | cin and 32 | cout: 64 x 64-channel
+ * blocks when both are multiples of 64, 32 x 32 blocks otherwise) */
 int ur_wgrad3x3_tile_supported(const ur_conv_desc* d);
 size_t ur_wgrad3x3_tile_workspace(const ur_conv_desc* d);
 int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,

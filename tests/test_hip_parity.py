@@ -56,6 +56,8 @@ CONV_SHAPES = [
     (1, 128, 9, 13, 192, 3, 1, 1, False),      # ragged spatial size, two column tiles
     (1, 64, 20, 70, 128, 3, 1, 1, False),      # ragged in both directions, three tile columns
     (1, 256, 8, 32, 64, 3, 1, 1, False),       # eight 32-channel slices
+    (2, 32, 13, 40, 32, 3, 1, 1, False),       # ResLayer4: 32-channel blocks in the backward-weight kernel, ragged tile
+    (1, 64, 10, 33, 96, 3, 1, 1, False),       # 2 x 3 blocks of 32 channels
     (2, 3, 17, 19, 64, 3, 1, 1, False),        # Cin = 3 (scalar gather)
     (2, 3, 32, 32, 64, 7, 2, 3, False),        # stem
     (2, 64, 16, 16, 128, 3, 2, 1, False),      # strided ResBlock conv

@@ -12,7 +12,11 @@ pids=()
 for s in "${SRCS[@]}"; do
     src="$HERE/$s.hip"
     obj="$OBJ/$s.o"
-    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/ur_common.h" -nt "$obj" ] || [ "$HERE/../../include/uresnet_hip.h" -nt "$obj" ]; then
+    stale=0
+    for dep in "$src" "$HERE"/*.h "$HERE/../../include/uresnet_hip.h"; do
+        if [ ! -f "$obj" ] || [ "$dep" -nt "$obj" ]; then stale=1; fi
+    done
+    if [ "$stale" = 1 ]; then
         ( $HIPCC $FLAGS -c "$src" -o "$obj" ) &
         pids+=($!)
     fi

@@ -4,6 +4,7 @@
 // CPG == 4: the quad is one group (4 in x 4 out).  CPG == 1: the quad is 4 independent channels.
 // Weights stay in PyTorch layout w[c_out][cpg][3][3] fp32 and are read through the cache.
 #include "ur_common.h"
+#include "wgrad32_tile.h"
 
 namespace {
 
@@ -333,149 +334,10 @@ __global__ __launch_bounds__(NT) void gconv3x3_wgrad_kernel(const T* __restrict_
     }
 }
 
-// Backward-weight for bf16, 4 channels per group, 32 | C, on the matrix cores.  For a block of 32 channels (8 groups)
-// the full 32 x 32 cross product  D[co][ci] = sum_pixels dy[p][co] * x[p + tap][ci]  costs one
-// v_mfma_f32_32x32x16_bf16 per tap and 16 pixels; only its eight 4x4 diagonal blocks are the grouped gradient, but the
-// matrix cores make the other seven eighths free next to the two tensor reads (the direct kernel above is bound
-// by its 144 multiply-adds per loaded quad).  Same scheme as the dense 3x3 backward-weight tile kernel: a workgroup
-// stages a 4 x 32-pixel dy tile and its 6 x 34 x halo in LDS (64 bytes per pixel), the reduction index is the pixel,
-// so both operands come from the transposing LDS read; wave w owns tile row w.  After the tile walk the four waves'
-// accumulators are summed through LDS and the diagonal blocks written as one partial row in weight layout.
-namespace gw {
-constexpr int TW = 32, TH = 4, HP = 36, HCOLS = 34;
-constexpr int DY_BYTES = TH * TW * 64, HALO_BYTES = (TH + 2) * HP * 64;
-constexpr int DY_ITERS = TH * TW * 4 / NT, HALO_PIECES = (TH + 2) * HCOLS * 4, HALO_ITERS = (HALO_PIECES + NT - 1) / NT;
-typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
-typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* base0, const unsigned char* base1, int imm) {
-    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base0 + imm));
-    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base1 + imm));
-    s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, both);
-}
-}  // namespace gw
-
-__global__ __launch_bounds__(NT, 2) void gconv3x3_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                    float* __restrict__ partial, int N, int H, int W, int C,
-                                                                    int tiles_x, int tiles_y, int tiles) {
-    using namespace gw;
-    constexpr int RED_BYTES = 4 * 16 * 64 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[DY_BYTES + HALO_BYTES > RED_BYTES ? DY_BYTES + HALO_BYTES : RED_BYTES];
-    unsigned char* dyl = lds;
-    unsigned char* xl = lds + DY_BYTES;
-    const int split = blockIdx.x, nsplit = gridDim.x, cb = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int piece = tid & 3;
-
-    bf16x8_t pd[DY_ITERS], ph[HALO_ITERS];
-    auto prefetch = [&](int tile) {
-        const int img = tile / (tiles_y * tiles_x);
-        const int trem = tile - img * (tiles_y * tiles_x);
-        const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
-        const bf16_t* dyb = dy + (size_t)img * H * W * C + cb * 32 + piece * 8;
-        const bf16_t* xb = x + (size_t)img * H * W * C + cb * 32 + piece * 8;
-#pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) {
-            const int pix = (tid >> 2) + j * (NT / 4);
-            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
-            if (oy < H && ox < W) pd[j] = *reinterpret_cast<const bf16x8_t*>(dyb + ((size_t)oy * W + ox) * C);
-            else pd[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int j = 0; j < HALO_ITERS; ++j) {
-            const int hp = (tid >> 2) + j * (NT / 4);
-            const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
-            const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-            if (hp < (TH + 2) * HCOLS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                ph[j] = *reinterpret_cast<const bf16x8_t*>(xb + ((size_t)gy * W + gx) * C);
-            else ph[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) {
-            const int pix = (tid >> 2) + j * (NT / 4);
-            *reinterpret_cast<bf16x8_t*>(dyl + pix * 64 + piece * 16) = pd[j];
-        }
-#pragma unroll
-        for (int j = 0; j < HALO_ITERS; ++j) {
-            const int hp = (tid >> 2) + j * (NT / 4);
-            const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
-            if (hp < (TH + 2) * HCOLS) *reinterpret_cast<bf16x8_t*>(xl + (hy * HP + hx) * 64 + piece * 16) = ph[j];
-        }
-    };
-
-    // transposing-read lane constants: 16-lane group g reads pixels 8 (g >> 1) + (li >> 2) (+4 for the second read),
-    // channels 16 (g & 1) + 4 (li & 3)
-    const int g = lane >> 4, li = lane & 15;
-    const int lpix = 8 * (g >> 1) + (li >> 2), lch = 16 * (g & 1) + 4 * (li & 3);
-    const unsigned char* a_base[2];
-    const unsigned char* b_base[3][2];
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        a_base[h2] = dyl + (wave * TW + lpix + 4 * h2) * 64 + lch * 2;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) b_base[dx][h2] = xl + (wave * HP + lpix + 4 * h2 + dx) * 64 + lch * 2;
-    }
-
-    f32x16_t acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    int tile = split;
-    if (tile < tiles) prefetch(tile);
-    for (; tile < tiles; tile += nsplit) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (tile + nsplit < tiles) prefetch(tile + nsplit);
-#pragma unroll
-        for (int kx = 0; kx < 2; ++kx) {
-            const bf16x8_t af = tr_frag(a_base[0], a_base[1], kx * 16 * 64);
-#pragma unroll
-            for (int dyk = 0; dyk < 3; ++dyk)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const bf16x8_t bfr = tr_frag(b_base[dx][0], b_base[dx][1], (dyk * HP + kx * 16) * 64);
-                    acc[dyk * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[dyk * 3 + dx], 0, 0, 0);
-                }
-        }
-    }
-
-    // sum the four waves' blocks tap by tap through LDS; keep the diagonal 4x4 blocks (co / 4 == ci / 4)
-    float* red = reinterpret_cast<float*>(lds);
-    const size_t wsz = (size_t)C * 4 * 9;
-    float* row = partial + (size_t)split * wsz;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int o = tid + NT * k, r = o >> 6, ln = o & 63;
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), ci = ln & 31;
-            if ((co >> 2) == (ci >> 2)) {
-                const float v = (red[(0 * 16 + r) * 64 + ln] + red[(1 * 16 + r) * 64 + ln]) +
-                                (red[(2 * 16 + r) * 64 + ln] + red[(3 * 16 + r) * 64 + ln]);
-                row[((size_t)(cb * 32 + co) * 4 + (ci & 3)) * 9 + t] = v;
-            }
-        }
-    }
-}
-
 static bool wgrad_mfma_ok(int dtype, int c, int cpg, const void* x, const void* dy) {
     return dtype == UR_BF16 && cpg == 4 && c % 32 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0;
 }
-static int wgrad_mfma_splits(int n, int h, int w, int c) {
-    const int tiles = n * ur_cdiv(h, gw::TH) * ur_cdiv(w, gw::TW);
-    int want = 512 / (c / 32);
-    if (want < 1) want = 1;
-    return want < tiles ? want : tiles;
-}
+static int wgrad_mfma_splits(int n, int h, int w, int c) { return wg32::splits(n, h, w, c / 32); }
 
 // dw[i] = sum_p partial[p][i], fixed summation order
 template <int SL>
@@ -534,14 +396,11 @@ int ur_gconv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace,
                       int w_, int c, int cpg, ur_stream_t s) {
     if (int e = check_args(x, dw, dy, dtype, n, h, w_, c, cpg)) return e;
     UR_REQUIRE(workspace && ws_bytes >= ur_gconv3x3_wgrad_workspace(n, h, w_, c, cpg), "gconv3x3_wgrad: workspace too small");
-    int grid = wgrad_blocks((long long)n * h * w_, c);
+    const int grid = wgrad_blocks((long long)n * h * w_, c);
     float* partial = (float*)workspace;
-    if (wgrad_mfma_ok(dtype, c, cpg, x, dy)) {
-        grid = wgrad_mfma_splits(n, h, w_, c);
-        const int tx = ur_cdiv(w_, gw::TW), ty = ur_cdiv(h, gw::TH);
-        hipLaunchKernelGGL(gconv3x3_wgrad_mfma_kernel, dim3(grid, c / 32), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)x,
-                           (const bf16_t*)dy, partial, n, h, w_, c, tx, ty, n * tx * ty);
-    } else UR_DISPATCH_DTYPE(dtype, {
+    if (wgrad_mfma_ok(dtype, c, cpg, x, dy))      // 32-channel blocks on the matrix cores, diagonal 4x4 blocks kept
+        return wg32::run<true>((const bf16_t*)x, (const bf16_t*)dy, dw, partial, n, h, w_, c, c, c, c, (hipStream_t)s);
+    UR_DISPATCH_DTYPE(dtype, {
         if (cpg == 1) hipLaunchKernelGGL((gconv3x3_wgrad_kernel<T, 1>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, (const T*)dy, partial, n, h, w_, c);
         else hipLaunchKernelGGL((gconv3x3_wgrad_kernel<T, 4>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)x, (const T*)dy, partial, n, h, w_, c);
     });

@@ -13,6 +13,7 @@
 // 72 MFMAs per tile per wave.  Partial blocks go to one fp32 slab per split and are summed in a
 // fixed order by a second kernel that also transposes to PyTorch's [co][ci][ky][kx].
 #include "ur_common.h"
+#include "wgrad32_tile.h"
 #include <stdlib.h>
 
 namespace {
@@ -211,12 +212,15 @@ Plan make_plan(const ur_conv_desc* d) {
     return pl;
 }
 
+// 1: the 64 x 64-block kernel; 2: the 32 x 32-block kernel (channel counts that are multiples of 32 but not both of 64)
 int supported(const ur_conv_desc* d) {
     if (!d || d->dtype != UR_BF16) return 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w)) return 0;
-    if (d->cout % BO != 0 || d->cin % BI != 0 || d->in_ld % 8 != 0 || d->out_ld % 8 != 0) return 0;
+    if (d->in_ld % 8 != 0 || d->out_ld % 8 != 0) return 0;
     if ((long long)d->n * d->h * d->w >= (1LL << 31)) return 0;
-    return 1;
+    if (d->cout % BO == 0 && d->cin % BI == 0) return 1;
+    if (d->cout % 32 == 0 && d->cin % 32 == 0) return 2;
+    return 0;
 }
 
 }  // namespace
@@ -227,16 +231,21 @@ int ur_wgrad3x3_tile_supported(const ur_conv_desc* d) { return supported(d); }
 
 size_t ur_wgrad3x3_tile_workspace(const ur_conv_desc* d) {
     if (!supported(d)) return 0;
+    if (supported(d) == 2)
+        return (size_t)wg32::splits(d->n, d->h, d->w, (d->cout / 32) * (d->cin / 32)) * d->cout * d->cin * 9 * sizeof(float);
     Plan pl = make_plan(d);
     return (size_t)pl.nsplit * d->cout * 9 * d->cin * sizeof(float);
 }
 
 int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
                      ur_stream_t s) {
-    UR_REQUIRE(supported(d), "wgrad3x3_tile: unsupported geometry (needs bf16, 3x3 s1 p1, 64 | cin, 64 | cout)");
+    UR_REQUIRE(supported(d), "wgrad3x3_tile: unsupported geometry (needs bf16, 3x3 s1 p1, 32 | cin, 32 | cout)");
     UR_REQUIRE(x && dy && dw && workspace, "wgrad3x3_tile: null pointer");
     UR_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "wgrad3x3_tile: tensors must be 16-byte aligned");
     UR_REQUIRE(ws_bytes >= ur_wgrad3x3_tile_workspace(d), "wgrad3x3_tile: workspace too small");
+    if (supported(d) == 2)
+        return wg32::run<false>((const bf16_t*)x, (const bf16_t*)dy, dw, (float*)workspace, d->n, d->h, d->w, d->cin, d->cout,
+                                d->in_ld, d->out_ld, (hipStream_t)s);
     Plan pl = make_plan(d);
     WgTileParams p{};
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.ws = (float*)workspace;
