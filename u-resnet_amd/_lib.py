@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liburesnet_hip.so")
+LIB_PATH = os.environ.get("URESNET_HIP_LIB") or os.path.join(_HERE, "lib", "liburesnet_hip.so")   # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "uresnet_hip.h")
 
 UR_F32, UR_BF16 = 0, 1
