@@ -1,4 +1,4 @@
-"""GPU parity at the sizes BASELINE.json names: one Cityscapes-shaped 512x1024 image through
+"""GPU parity at the headline benchmark size: one Cityscapes-shaped 512x1024 image through
 UResNetNewEUCB(19,3,64) (config 3), one 224x224 MiniImageNet batch through U_ResNet(100,3) (config 2)
 and the Ice-Seg inference path (config 5), each against the CPU oracle run on the same seeded inputs."""
 import numpy as np
