@@ -127,7 +127,9 @@ __device__ __forceinline__ int halo_lds_offset(int hy, int hx, int piece) {
     return hy * ROW_BYTES + hx * 32 + ((piece ^ ((hx >> 3) & 1)) << 4);
 }
 
-template <int R>
+// EPI selects the epilogue at compile time (run-time options turn into hundreds of selects on the 128 accumulators):
+// 0 = rounded result (+ per-channel statistics), 1 = + addend, 2 = folded BatchNorm (scale, shift, optional residual, ReLU)
+template <int R, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p) {
     using G = Geo<R>;
     using S = Sched<R>;
@@ -308,59 +310,93 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
     // ---- epilogue: per-channel partial statistics of the fp32 results, bf16 tile via LDS -> 16-byte stores ----
     unsigned char* ostage = lds + wave * (R * TW * OUT_PITCH);
     float* red = reinterpret_cast<float*>(lds + G::OUT_BYTES);
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    float aff_sc[2] = {1.f, 1.f}, aff_sh[2] = {0.f, 0.f};
-    if (p.scale) {
+    const bool interior = ty0 + G::TH <= p.H && tx0 + TW <= p.W;        // no pixel of the tile lies outside the image
+    if constexpr (EPI == 2) {
+        float sc[2], sh[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { aff_sc[b] = p.scale[nb * BN + b * 32 + lx]; aff_sh[b] = p.shift[nb * BN + b * 32 + lx]; }
-    }
+        for (int b = 0; b < 2; ++b) { sc[b] = p.scale[nb * BN + b * 32 + lx]; sh[b] = p.shift[nb * BN + b * 32 + lx]; }
+        const bool relu_now = p.relu && !p.addend;
 #pragma unroll
-    for (int a = 0; a < R; ++a) {
-        const int oy = ty0 + wave * R + a;
+        for (int a = 0; a < R; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[a][b][r];
-                if (p.scale) {
-                    v = v * aff_sc[b] + aff_sh[b];
-                    if (p.relu && !p.addend) v = fmaxf(v, 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[a][b][r] * sc[b] + sh[b];
+                    acc[a][b][r] = relu_now ? fmaxf(v, 0.f) : v;
                 }
-                *reinterpret_cast<bf16_t*>(ostage + (a * TW + px) * OUT_PITCH + (b * 32 + lx) * 2) = (bf16_t)v;
-                if (oy < p.H && tx0 + px < p.W) { s1[b] += v; s2[b] += v * v; }
+    }
+    if (EPI == 0 && p.stats) {
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        if (interior) {
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float v = acc[a][b][r]; s1[b] += v; s2[b] += v * v; }
+        } else {
+#pragma unroll
+            for (int a = 0; a < R; ++a) {
+                const int oy = ty0 + wave * R + a;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float v = (oy < p.H && tx0 + px < p.W) ? acc[a][b][r] : 0.f;
+                        s1[b] += v; s2[b] += v * v;
+                    }
             }
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < R * 4; ++i) {
-        const int idx = lane + 64 * i;
-        const int pxl = idx >> 3, piece = idx & 7;
-        const int oy = ty0 + wave * R + (pxl >> 5), ox = tx0 + (pxl & 31);
-        if (oy < p.H && ox < p.W) {
-            const size_t pix = (size_t)(img * p.H + oy) * p.W + ox;
-            bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ostage + pxl * OUT_PITCH + piece * 16);
-            if (p.addend) {
-                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float t = (float)v[k] + (float)a[k];
-                    if (p.relu) t = fmaxf(t, 0.f);
-                    v[k] = (bf16_t)t;
-                }
-            }
-            *reinterpret_cast<bf16x8_t*>(p.y + pix * p.ld_out + nb * BN + piece * 8) = v;
-        }
-    }
-    if (p.stats) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const float t1 = s1[b] + __shfl_xor(s1[b], 32, 64);
             const float t2 = s2[b] + __shfl_xor(s2[b], 32, 64);
             if (lh == 0) { red[(wave * BN + b * 32 + lx) * 2] = t1; red[(wave * BN + b * 32 + lx) * 2 + 1] = t2; }
         }
+    }
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                *reinterpret_cast<bf16_t*>(ostage + (a * TW + px) * OUT_PITCH + (b * 32 + lx) * 2) = (bf16_t)acc[a][b][r];
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto store_piece = [&](int i, bool check) {
+        const int idx = lane + 64 * i;
+        const int pxl = idx >> 3, piece = idx & 7;
+        const int oy = ty0 + wave * R + (pxl >> 5), ox = tx0 + (pxl & 31);
+        if (!check || (oy < p.H && ox < p.W)) {
+            const size_t pix = (size_t)(img * p.H + oy) * p.W + ox;
+            bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ostage + pxl * OUT_PITCH + piece * 16);
+            if constexpr (EPI != 0) {
+                if (EPI == 1 || p.addend) {
+                    const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
+                    const bool relu = EPI == 2 && p.relu;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float t = (float)v[k] + (float)ad[k];
+                        if (relu) t = fmaxf(t, 0.f);
+                        v[k] = (bf16_t)t;
+                    }
+                }
+            }
+            *reinterpret_cast<bf16x8_t*>(p.y + pix * p.ld_out + nb * BN + piece * 8) = v;
+        }
+    };
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < R * 4; ++i) store_piece(i, false);
+    } else {
+#pragma unroll
+        for (int i = 0; i < R * 4; ++i) store_piece(i, true);
+    }
+    if (EPI == 0 && p.stats) {
         __syncthreads();
         if (tid < BN) {
             float* o = p.stats + ((size_t)tile * p.Cout + nb * BN + tid) * 2;
@@ -466,8 +502,11 @@ int launch(const void* src, const void* wpk, void* dst, float* stats, const ur_c
     p.tiles = d->n * p.tiles_x * p.tiles_y;
     p.nblocks = p.Cout / BN;
     const int grid = ((p.tiles + 7) / 8 * 8) * p.nblocks;
-    if (R == 4) hipLaunchKernelGGL(conv3x3_tile_kernel<4>, dim3(grid), dim3(NTHREADS), 0, st, p);
-    else hipLaunchKernelGGL(conv3x3_tile_kernel<2>, dim3(grid), dim3(NTHREADS), 0, st, p);
+    const int epi = scale ? 2 : (addend ? 1 : 0);
+#define UR_TILE_LAUNCH(RR, EE) hipLaunchKernelGGL((conv3x3_tile_kernel<RR, EE>), dim3(grid), dim3(NTHREADS), 0, st, p)
+    if (R == 4) { if (epi == 0) UR_TILE_LAUNCH(4, 0); else if (epi == 1) UR_TILE_LAUNCH(4, 1); else UR_TILE_LAUNCH(4, 2); }
+    else { if (epi == 0) UR_TILE_LAUNCH(2, 0); else if (epi == 1) UR_TILE_LAUNCH(2, 1); else UR_TILE_LAUNCH(2, 2); }
+#undef UR_TILE_LAUNCH
     return ur_check_launch("conv3x3_tile");
 }
 
