@@ -294,10 +294,34 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmParams p) {
     if (p.vec_store) {
         // The accumulator layout gives a lane one column and 32 rows; stores of one element per lane would be
         // 2-4 bytes each.  Stage each 64 x 32 sub-tile in the wave's own rows of As (no other wave reads them)
-        // and write it back out as 16-byte row pieces.
+        // and write it back out as 16-byte row pieces.  Layers with short reductions spend more time here than in
+        // the slice loop, so the common case (full tile, 32 | channels of a transposed-convolution tap) takes a
+        // path without per-element bounds tests, divisions or statistics it does not need.
         constexpr int VE = 16 / (int)sizeof(T);      // elements per 16-byte piece
         constexpr int CPR = 32 / VE;                 // pieces per 32-column row
         T* stage = As + wave * 64 * PITCH;
+        const bool full = m0 + BM <= p.M && n0 + BN <= p.Ncols;
+        float bv[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = n0 + b * 32 + lrow;
+            bv[b] = (p.bias && n < p.Ncols) ? p.bias[p.scatter ? n % p.cout_t : n] : 0.f;
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const bool nok = n0 + b * 32 + lrow < p.Ncols;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                        float v = acc[a][b][r] + bv[b];
+                        if (!full) v = (m0 + wave * 64 + row < p.M && nok) ? v : 0.f;
+                        s1[b] += v; s2[b] += v * v;
+                    }
+            }
+        }
         size_t rowoff[CPR];
         bool rowok[CPR];
 #pragma unroll
@@ -314,32 +338,33 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmParams p) {
                 rowoff[i] = ((size_t)(img * 2 * p.OH + 2 * y) * (2 * p.OW) + 2 * x) * p.dst_ld;
             }
         }
+        const bool tap_uniform = p.scatter && p.cout_t % 32 == 0;      // a 32-column sub-tile lies inside one tap
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
-            const int n = n0 + b * 32 + lrow;
-            const bool nok = n < p.Ncols;
-            const float bv = (p.bias && nok) ? p.bias[p.scatter ? n % p.cout_t : n] : 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    const float v = acc[a][b][r] + bv;
-                    stage[row * PITCH + lrow] = ur_from_float<T>(v);
-                    if (m0 + wave * 64 + row < p.M && nok) { s1[b] += v; s2[b] += v * v; }
+                    stage[row * PITCH + lrow] = ur_from_float<T>(acc[a][b][r] + bv[b]);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            size_t coloff = (size_t)(n0 + b * 32);                      // column offset of the sub-tile, plain layout
+            if (tap_uniform) {
+                const int tap = (n0 + b * 32) / p.cout_t, co = (n0 + b * 32) - tap * p.cout_t;
+                coloff = ((size_t)(tap >> 1) * (2 * p.OW) + (tap & 1)) * p.dst_ld + co;
+            }
 #pragma unroll
             for (int i = 0; i < CPR; ++i) {
                 const int idx = lane + 64 * i;
                 const int row = idx / CPR, piece = idx % CPR;
                 const int nn = n0 + b * 32 + piece * VE;
-                if (rowok[i] && nn < p.Ncols) {
+                if (full || (rowok[i] && nn < p.Ncols)) {
                     size_t off;
-                    if (!p.scatter) {
-                        off = rowoff[i] + nn;
+                    if (!p.scatter || tap_uniform) {
+                        off = rowoff[i] + coloff + piece * VE;
                     } else {
                         const int tap = nn / p.cout_t, co = nn - tap * p.cout_t;
                         off = rowoff[i] + ((size_t)(tap >> 1) * (2 * p.OW) + (tap & 1)) * p.dst_ld + co;
