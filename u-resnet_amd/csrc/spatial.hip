@@ -12,11 +12,15 @@ constexpr int NT = 256;
 template <typename T, int V> struct Pack {
     float v[V];
     __device__ __forceinline__ void load(const T* p) {
-        if constexpr (V == 4) { float4 f = ur_load4(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+        if constexpr (V == 8) {                       // 16 bytes of bf16 (two 16-byte halves for fp32)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { float4 f = ur_load4(p + 4 * h); v[4 * h] = f.x; v[4 * h + 1] = f.y; v[4 * h + 2] = f.z; v[4 * h + 3] = f.w; }
+        } else if constexpr (V == 4) { float4 f = ur_load4(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
         else v[0] = ur_to_float(*p);
     }
     __device__ __forceinline__ void store(T* p) const {
-        if constexpr (V == 4) ur_store4(p, make_float4(v[0], v[1], v[2], v[3]));
+        if constexpr (V == 8) { ur_store4(p, make_float4(v[0], v[1], v[2], v[3])); ur_store4(p + 4, make_float4(v[4], v[5], v[6], v[7])); }
+        else if constexpr (V == 4) ur_store4(p, make_float4(v[0], v[1], v[2], v[3]));
         else *p = ur_from_float<T>(v[0]);
     }
     __device__ __forceinline__ void fill(float x) {
@@ -24,6 +28,48 @@ template <typename T, int V> struct Pack {
         for (int i = 0; i < V; ++i) v[i] = x;
     }
 };
+
+template <> struct Pack<bf16_t, 8> {
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        bf16x8_t t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+        *reinterpret_cast<bf16x8_t*>(p) = t;
+    }
+    __device__ __forceinline__ void fill(float x) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = x;
+    }
+};
+
+// V window-position bytes of the max-pool index, as one 4- or 8-byte access when V allows
+template <int V> __device__ __forceinline__ void store_sel(uint8_t* p, const uint8_t* sel) {
+    if constexpr (V == 8) {
+        unsigned long long w = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w |= (unsigned long long)sel[k] << (8 * k);
+        *reinterpret_cast<unsigned long long*>(p) = w;
+    } else if constexpr (V == 4) {
+        *reinterpret_cast<unsigned*>(p) = sel[0] | (sel[1] << 8) | (sel[2] << 16) | (sel[3] << 24);
+    } else p[0] = sel[0];
+}
+template <int V> __device__ __forceinline__ void load_sel(const uint8_t* p, uint8_t* sel) {
+    if constexpr (V == 8) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long*>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sel[k] = (uint8_t)(w >> (8 * k));
+    } else if constexpr (V == 4) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sel[k] = (uint8_t)(w >> (8 * k));
+    } else sel[0] = p[0];
+}
 
 // 64-bit division costs ~100 instructions on the GPU: index arithmetic is 32-bit (hosts check totals < 2^31)
 #define GRID_STRIDE(i, total) \
@@ -56,8 +102,7 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
             o.v[k] = m; sel[k] = (uint8_t)s;
         }
         o.store(y + (size_t)pix * C + cv * V);
-#pragma unroll
-        for (int k = 0; k < V; ++k) idx[(size_t)pix * C + cv * V + k] = sel[k];
+        store_sel<V>(idx + (size_t)pix * C + cv * V, sel);
     }
 }
 
@@ -79,8 +124,10 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ d
             long long op = (((long long)n * OH + oy) * OW + ox) * C + cv * V;
             Pack<T, V> g; g.load(dy + op);
             const int me = (iy & 1) * 2 + (ix & 1);
+            uint8_t sel[V];
+            load_sel<V>(idx + op, sel);
 #pragma unroll
-            for (int k = 0; k < V; ++k) o.v[k] = idx[op + k] == me ? g.v[k] : 0.f;
+            for (int k = 0; k < V; ++k) o.v[k] = sel[k] == me ? g.v[k] : 0.f;
         }
         if (addend) {                                   // a second gradient of the pooled tensor (its skip connection)
             Pack<T, V> a; a.load(addend + (size_t)pix * add_ld + cv * V);
@@ -368,7 +415,8 @@ __global__ __launch_bounds__(NT) void remap_labels_kernel(const uint8_t* __restr
 
 #define SPATIAL_LAUNCH(kernel, total, ...)                                                                     \
     UR_DISPATCH_DTYPE(dtype, {                                                                                 \
-        if (vec) hipLaunchKernelGGL((kernel<T, 4>), dim3(ur_grid_1d((total) / 4, NT)), dim3(NT), 0, (hipStream_t)s, __VA_ARGS__); \
+        if (vec8) hipLaunchKernelGGL((kernel<T, 8>), dim3(ur_grid_1d((total) / 8, NT)), dim3(NT), 0, (hipStream_t)s, __VA_ARGS__); \
+        else if (vec) hipLaunchKernelGGL((kernel<T, 4>), dim3(ur_grid_1d((total) / 4, NT)), dim3(NT), 0, (hipStream_t)s, __VA_ARGS__); \
         else hipLaunchKernelGGL((kernel<T, 1>), dim3(ur_grid_1d((total), NT)), dim3(NT), 0, (hipStream_t)s, __VA_ARGS__);        \
     })
 
@@ -379,6 +427,7 @@ int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, in
     if (x_ld == 0) x_ld = c;
     UR_REQUIRE(x_ld >= c, "maxpool_fwd: input pitch %d smaller than the channel count %d", x_ld, c);
     const bool vec = c % 4 == 0 && x_ld % 4 == 0 && al(x, 4 * esize(dtype)) && al(y, 4 * esize(dtype));
+    const bool vec8 = dtype == UR_BF16 && c % 8 == 0 && x_ld % 8 == 0 && al(x, 16) && al(y, 16) && al(idx, 8);
     const long long total = (long long)n * (h / 2) * (w / 2) * c;
     UR_REQUIRE_32BIT(total, "maxpool_fwd");
     SPATIAL_LAUNCH(maxpool_fwd_kernel, total, (const T*)x, (T*)y, idx, n, h, w, c, x_ld);
@@ -392,6 +441,8 @@ int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, const void* 
     UR_REQUIRE(!addend || add_ld >= c, "maxpool_bwd: addend pitch %d is smaller than the channel count %d", add_ld, c);
     const bool vec = c % 4 == 0 && al(dy, 4 * esize(dtype)) && al(dx, 4 * esize(dtype)) &&
                      (!addend || (al(addend, 4 * esize(dtype)) && add_ld % 4 == 0));
+    const bool vec8 = dtype == UR_BF16 && c % 8 == 0 && al(dy, 16) && al(dx, 16) && al(idx, 8) &&
+                      (!addend || (al(addend, 16) && add_ld % 8 == 0));
     const long long total = (long long)n * h * w * c;
     UR_REQUIRE_32BIT(total, "maxpool_bwd");
     SPATIAL_LAUNCH(maxpool_bwd_kernel, total, (const T*)dy, idx, (T*)dx, (const T*)addend, add_ld, n, h, w, c);
@@ -401,6 +452,7 @@ int ur_maxpool2x2_bwd(const void* dy, const uint8_t* idx, void* dx, const void* 
 int ur_upsample_bilinear_fwd(const void* x, void* y, int dtype, int n, int h, int w, int c, int scale, ur_stream_t s) {
     UR_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && scale >= 1, "upsample_fwd: bad arguments");
     const bool vec = c % 4 == 0 && al(x, 4 * esize(dtype)) && al(y, 4 * esize(dtype));
+    const bool vec8 = dtype == UR_BF16 && c % 8 == 0 && al(x, 16) && al(y, 16);
     const long long total = (long long)n * h * scale * w * scale * c;
     UR_REQUIRE_32BIT(total, "upsample_fwd");
     const float rscale = (float)(1.0 / (double)scale);
@@ -411,6 +463,7 @@ int ur_upsample_bilinear_fwd(const void* x, void* y, int dtype, int n, int h, in
 int ur_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int n, int h, int w, int c, int scale, ur_stream_t s) {
     UR_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && scale >= 1, "upsample_bwd: bad arguments");
     const bool vec = c % 4 == 0 && al(dy, 4 * esize(dtype)) && al(dx, 4 * esize(dtype));
+    const bool vec8 = dtype == UR_BF16 && c % 8 == 0 && al(dy, 16) && al(dx, 16);
     const long long total = (long long)n * h * w * c;
     UR_REQUIRE_32BIT(total, "upsample_bwd");
     const float rscale = (float)(1.0 / (double)scale);
@@ -445,6 +498,7 @@ int ur_copy_channels(const void* src, int src_ld, int src_coff, int sh, int sw, 
     const char* sp = (const char*)src + (size_t)src_coff * es;
     char* dp = (char*)dst + (size_t)dst_coff * es;
     const bool vec = c % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0 && al(sp, 4 * es) && al(dp, 4 * es);
+    const bool vec8 = dtype == UR_BF16 && c % 8 == 0 && src_ld % 8 == 0 && dst_ld % 8 == 0 && al(sp, 16) && al(dp, 16);
     const long long total = (long long)n * dh * dw * c;
     UR_REQUIRE_32BIT(total, "copy_channels");
     SPATIAL_LAUNCH(copy_channels_kernel, total, (const T*)sp, src_ld, sh, sw, (T*)dp, dst_ld, dh, dw, pad_t, pad_l, n, c);
