@@ -1,11 +1,21 @@
 // Multi-tensor optimiser steps: one launch updates every parameter tensor of the model.
 // blockIdx.y selects the tensor (pointer table in device memory), blockIdx.x grid-strides over
-// its elements with float4 accesses; fp32 master weights, fp32 moments.
+// its elements (Adam: float4 accesses); fp32 master weights, fp32 moments.
 #include "ur_common.h"
 
 namespace {
 
 constexpr int NT = 256;
+
+__device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float beta1, float beta2, float eps,
+                                         float wd, float bc2_sqrt, float step_size, float grad_scale) {
+    gi *= grad_scale;
+    if (wd != 0.f) gi += wd * pi;
+    mi = mi + (gi - mi) * (1.f - beta1);                        // lerp form used by torch.optim.Adam
+    vi = vi * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+}
 
 __global__ __launch_bounds__(NT) void adam_multi_kernel(const void* const* __restrict__ ptrs,
                                                         const long long* __restrict__ sizes, float lr, float beta1,
@@ -18,15 +28,22 @@ __global__ __launch_bounds__(NT) void adam_multi_kernel(const void* const* __res
     float* __restrict__ v = (float*)ptrs[t * 4 + 3];
     const long long n = sizes[t];
     const float step_size = lr / bc1;
-    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
-        float gi = g[i] * grad_scale;
-        float pi = p[i];
-        if (wd != 0.f) gi += wd * pi;
-        float mi = m[i] + (gi - m[i]) * (1.f - beta1);          // lerp form used by torch.optim.Adam
-        float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
-        float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - step_size * (mi / denom);
-        m[i] = mi; v[i] = vi;
+    // 16-byte accesses over the aligned body (workgroups beyond a small tensor's length leave at once), scalar tail
+    const bool al16 = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const long long n4 = al16 ? n / 4 : 0;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+        const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+        adam_one(p4.x, g4.x, m4.x, v4.x, beta1, beta2, eps, wd, bc2_sqrt, step_size, grad_scale);
+        adam_one(p4.y, g4.y, m4.y, v4.y, beta1, beta2, eps, wd, bc2_sqrt, step_size, grad_scale);
+        adam_one(p4.z, g4.z, m4.z, v4.z, beta1, beta2, eps, wd, bc2_sqrt, step_size, grad_scale);
+        adam_one(p4.w, g4.w, m4.w, v4.w, beta1, beta2, eps, wd, bc2_sqrt, step_size, grad_scale);
+        reinterpret_cast<float4*>(p)[i] = p4; reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4;
+    }
+    for (long long i = n4 * 4 + blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_one(pi, g[i], mi, vi, beta1, beta2, eps, wd, bc2_sqrt, step_size, grad_scale);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 
@@ -45,10 +62,11 @@ __global__ __launch_bounds__(NT) void sgd_multi_kernel(const void* const* __rest
     }
 }
 
+// workgroups per tensor, sized for the largest one (16 elements per thread); the others' surplus workgroups exit
 int blocks_for(long long max_size) {
-    long long b = (max_size + NT * 8 - 1) / (NT * 8);
+    long long b = (max_size + NT * 16 - 1) / (NT * 16);
     if (b < 1) b = 1;
-    if (b > 128) b = 128;
+    if (b > 1024) b = 1024;
     return (int)b;
 }
 
