@@ -4,7 +4,7 @@ import glob
 import os
 import torch
 
-SHAPES = [(6 * 512 * 1024, 64), (6 * 256 * 512, 128), (6 * 64 * 128, 512)]
+SHAPES = [(6 * 512 * 1024, 32), (6 * 512 * 1024, 80), (6 * 512 * 1024, 64), (6 * 256 * 512, 128), (6 * 64 * 128, 512)]
 
 
 def main():
@@ -34,13 +34,14 @@ def main():
             aargs = (C.c_void_p(dz.data_ptr()), C.c_void_p(y.data_ptr()), None, C.c_void_p(mean.data_ptr()),
                      C.c_void_p(invstd.data_ptr()), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
                      C.c_void_p(sums.data_ptr()), 1, 0, C.c_void_p(z.data_ptr()), None, 1, C.c_longlong(rows), c, 0, st)
-            runs.append((os.path.basename(path), lib, args, part, fargs, aargs, z, sums))
+            sargs = (C.c_void_p(y.data_ptr()), 1, C.c_longlong(rows), c, C.c_void_p(part.data_ptr()), st)
+            runs.append((os.path.basename(path), lib, args, part, fargs, aargs, z, sums, sargs))
         best = {}
         for rep in range(3):
             for r in runs:
                 name, lib = r[0], r[1]
                 for kind, fn, a, passes in (("reduce", lib.ur_bn_act_bwd_reduce, r[2], 2), ("fwd", lib.ur_bn_act_fwd, r[4], 2),
-                                            ("apply", lib.ur_bn_act_bwd_apply, r[5], 3)):
+                                            ("apply", lib.ur_bn_act_bwd_apply, r[5], 3), ("stats", lib.ur_bn_stats, r[8], 1)):
                     for _ in range(5):
                         assert fn(*a) == 0
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

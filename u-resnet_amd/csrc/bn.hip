@@ -498,7 +498,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
 
 // Backward reduction for bf16 with 8 channels per thread: thread (row slot, channel group) keeps its constants in
 // registers and has U rows (16-byte loads of dz, y and optionally z) in flight before the first use.
-// Requires C % 8 == 0 and NT % (C / 8) == 0.
+// Requires C % 8 == 0 and C / 8 <= NT.
 #ifndef UR_BN_RED8_UNROLL
 #define UR_BN_RED8_UNROLL 2
 #endif
@@ -532,6 +532,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_bf16x8_kernel(
     };
     const long long step = (long long)gridDim.x * slots;
     long long r = (long long)blockIdx.x * slots + slot;
+    if (slot >= slots) r = rows;                    // NT is not a multiple of C / 8: the surplus threads add nothing
     const bf16_t* py = y + r * C + col;
     const bf16_t* pz = z + r * C + col;
     const bf16_t* pg = dz + r * (PITCHED ? dz_ld : C) + col;
@@ -709,7 +710,7 @@ int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const flo
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, V, true>), dim3(grid), dim3(NT), 0, (hipStream_t)s,            \
                                 (const TT*)dz, (const TT*)y, (const TT*)z, mean, invstd, gamma, beta, act, rows, c, dz_ld, partial); \
     } while (0)
-    if (dtype == UR_BF16 && vec && c % 8 == 0 && NT % (c / 8) == 0 && (dz_ld * 2) % 16 == 0 && aligned16(mean) &&
+    if (dtype == UR_BF16 && vec && c % 8 == 0 && c / 8 <= NT && (dz_ld * 2) % 16 == 0 && aligned16(mean) &&
         aligned16(invstd) && (!act || z || (aligned16(gamma) && aligned16(beta)))) {
         const bool have_z = act && z;
         const float* ga = gamma ? gamma : mean;        // constants are loaded unconditionally, then overridden
