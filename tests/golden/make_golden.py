@@ -7,6 +7,7 @@ and stores inputs + outputs as small .npz fixtures next to this script.  The
 fixtures are data only: tensors, scalars and sha256 digests.
 
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py temp       # only the scratch-variant models of Classification/modules/temp.py
 """
 import hashlib
 import importlib.util
@@ -24,6 +25,7 @@ FILES = {
     "ice": "Segmentation/Ice-Seg/modules/U_ResNet.py",
     "cifar": "Classification/modules/U_ResNet_CIFAR.py",
     "mini": "Classification/modules/U_ResNet_MiniImageNet.py",
+    "temp": "Classification/modules/temp.py",
 }
 
 
@@ -255,6 +257,20 @@ def cls_model_case(name, build, nclass, shape, lr, steps=3):
 
 def main():
     torch.set_num_threads(8)
+    if "temp" not in sys.argv[1:]:
+        main_families()
+    temp = load_ref("temp")
+    only = [a for a in sys.argv[1:] if a != "temp"]
+    global cls_model_case
+    every = cls_model_case
+    cls_model_case = lambda name, *a, **k: every(name, *a, **k) if not only or name in only else None
+    cls_model_case("temp_nlnet", lambda: temp.NlNet(100, 3), 100, (2, 3, 224, 224), 0.01, steps=2)
+    cls_model_case("temp_uresnet2", lambda: temp.UResNet2(100, 3), 100, (2, 3, 224, 224), 0.01, steps=1)
+    cls_model_case("temp_eresnet", lambda: temp.E_ResNet(100, 3), 100, (2, 3, 224, 224), 0.01, steps=1)
+    cls_model_case("temp_uresnet", lambda: temp.U_ResNet(100, 3), 100, (2, 3, 224, 224), 0.01, steps=1)
+
+
+def main_families():
     seg, ice, cifar, mini = (load_ref(t) for t in ("seg", "ice", "cifar", "mini"))
     module_case("basicblock_64_64", lambda: seg.BasicBlock(64, 64), [(2, 64, 8, 32)], eval_after=True)
     module_case("basicblock_64_128", lambda: seg.BasicBlock(64, 128), [(2, 64, 8, 32)])

@@ -78,6 +78,19 @@ def test_cifar_state_dict_layout():
     assert sha == list(rec["w0_sha"])
 
 
+@pytest.mark.parametrize("name, cls", [("temp_nlnet", "NlNet"), ("temp_uresnet2", "UResNet2"),
+                                       ("temp_eresnet", "E_ResNet"), ("temp_uresnet", "U_ResNet")])
+def test_temp_variant_state_dict_layout(name, cls):
+    import hashlib
+    from uresnet_amd.modules import temp as M
+    rec = load_golden(name)
+    torch.manual_seed(0)
+    sd = getattr(M, cls)(100, 3).state_dict()
+    assert list(sd.keys()) == list(rec["keys"])
+    sha = [hashlib.sha256(v.contiguous().numpy().tobytes()).hexdigest() for v in sd.values()]
+    assert sha == list(rec["w0_sha"])
+
+
 def test_constructor_signatures_follow_the_reference():
     from uresnet_amd.modules import U_ResNet as S, U_ResNet_CIFAR as Cc, U_ResNet_MiniImageNet as Cm
     sig = lambda c: list(inspect.signature(c.__init__).parameters)[1:]

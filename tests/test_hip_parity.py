@@ -464,6 +464,32 @@ def test_cifar_model_fp32_matches_reference(pkg):
     assert np.allclose(losses, rec["losses"], rtol=2e-3), (losses, rec["losses"])
 
 
+@pytest.mark.parametrize("name, cls", [("temp_nlnet", "NlNet"), ("temp_uresnet2", "UResNet2"),
+                                       ("temp_eresnet", "E_ResNet"), ("temp_uresnet", "U_ResNet")])
+def test_temp_variant_fp32_matches_reference(pkg, name, cls):
+    """Scratch variants of Classification/modules/temp.py at 224x224: AvgPool2d(9, 9) on a 28x28 map, a 3x3 -> 6x6
+    transposed convolution padded to its 7x7 skip, 2048-channel convolutions."""
+    rec = load_golden(name)
+    torch.manual_seed(0)
+    m = getattr(pkg.modules.temp, cls)(100, 3).set_compute_dtype(torch.float32)
+    m.to(DEV).train()
+    x, y = torch.from_numpy(rec["x"]).to(DEV), torch.from_numpy(rec["target"]).to(DEV)
+    opt = pkg.train.SGD(m.parameters(), lr=0.01)
+    losses = []
+    for s in range(len(rec["losses"])):
+        loss, out = pkg.train.cls_train_step(m, opt, x, y)
+        losses.append(loss.item())
+        if s == 0:
+            assert rel_l2(out.float().cpu(), rec["logits"]) < 2e-4
+            assert [k for k, p in m.named_parameters() if p.grad is None] == list(rec["nograd_keys"])
+            floor = 1e-5 * float(rec["grad_norm"].max())
+            errs = [abs(p.grad.double().norm().item() - n) / n
+                    for (k, p), n in zip([(k, p) for k, p in m.named_parameters() if p.grad is not None], rec["grad_norm"])
+                    if n > floor]
+            assert np.median(errs) < 1e-4 and max(errs) < 3e-2, (np.median(errs), max(errs))
+    assert np.allclose(losses, rec["losses"], rtol=2e-3), (losses, rec["losses"])
+
+
 # ----------------------------------------------------------------------------- fused concatenation paths
 def test_channel_window_ops_are_bit_exact(pkg):
     """BatchNorm+ReLU into a channel window, max-pool from a window, ConvTranspose into a window == the dense ops."""

@@ -150,3 +150,31 @@ def test_cifar_model_matches_reference(oracle):
             nograd = [k for k, p in m.named_parameters() if p.grad is None]
             assert nograd == list(rec["nograd_keys"])       # U_Net.up4.* never receives a gradient
     assert np.allclose(losses, rec["losses"], rtol=1e-4)
+
+
+TEMP_CASES = {"temp_nlnet": "TempNlNet", "temp_uresnet2": "TempUResNet2", "temp_eresnet": "TempE_ResNet",
+              "temp_uresnet": "TempU_ResNet"}
+
+
+@pytest.mark.parametrize("name", sorted(TEMP_CASES))
+def test_temp_variant_matches_reference(oracle, name):
+    """The scratch variants of Classification/modules/temp.py at 224x224 (fixtures made from the reference file)."""
+    rec = load_golden(name)
+    torch.manual_seed(0)
+    m = getattr(oracle, TEMP_CASES[name])(100, 3)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(rec["keys"])
+    assert [_sha(v) for v in sd.values()] == list(rec["w0_sha"])
+    m.train()
+    x, y = torch.from_numpy(rec["x"]), torch.from_numpy(rec["target"])
+    opt = torch.optim.SGD(m.parameters(), lr=0.01)
+    losses = []
+    for s in range(len(rec["losses"])):
+        loss, out = oracle.cls_train_step(m, opt, x, y)
+        losses.append(loss.item())
+        if s == 0:
+            assert rel_l2(out, rec["logits"]) < 1e-5
+            assert [k for k, p in m.named_parameters() if p.grad is None] == list(rec["nograd_keys"])
+            for (k, p), n in zip([(k, p) for k, p in m.named_parameters() if p.grad is not None], rec["grad_norm"]):
+                assert abs(p.grad.double().norm().item() - n) <= 1e-3 * n + 1e-6, k
+    assert np.allclose(losses, rec["losses"], rtol=1e-4)
