@@ -36,9 +36,24 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--all-kernel-timing", action="store_true",
+                    help="bracket every convolution and BatchNorm launch with events (adds about 1 ms per step); "
+                         "the default brackets only the dominant kernel's launches")
     ap.add_argument("--per-shape", action="store_true", help="print per-(kernel, shape) conv timings to stderr")
     ap.add_argument("--per-shape-top", type=int, default=40)
     return ap.parse_args()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed counter summary (profiles/*_pmc_traffic.json, made by
+    tools/pmc_bench.sh + tools/pmc_traffic.py from two rocprofv3 --pmc passes over this same default workload).
+    Hardware counters cannot be read from inside the timed process, so this is the one number not measured live."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    rec = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    return (rec["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if rec else (None, None)
 
 
 def cpu_baseline(height, width):
@@ -120,6 +135,7 @@ def main():
     fence()
     if not args.no_kernel_timing:
         ops.kernel_timings = []
+        ops.kernel_timing_tags = None if args.all_kernel_timing else {"tile_fwd", "tile_dgrad"}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
@@ -163,8 +179,20 @@ def main():
                                      "flops_per_launch": fl / n, "time_share_of_step": round(sec / elapsed, 3)}
             dominant = max(summary, key=lambda k: summary[k]["time_share_of_step"])
             dom = summary.pop(dominant)
+            traffic = source = None
+            default_workload = (B, H, W, args.dtype, world) == (6, 512, 1024, "bf16", 1)
+            if default_workload and dominant.startswith("conv3x3_tile_kernel"):
+                traffic, source = pmc_traffic("conv3x3_tile_kernel")
+            # operands of the dominant group's launches: activations in and out once, the weight image once
+            esz = 2 if dtype == torch.bfloat16 else 4
+            dom_bytes = [(n_ * h_ * w_ * (ci + co) + ci * co * k_ * k_) * esz
+                         for (tag, shp), (cnt, _, _) in shapes.items() if tag in groups[dominant] and shp
+                         for (n_, h_, w_, ci, co, k_, _s) in [shp] for _ in range(cnt)]
             roof = {"bound": "mfma", "kernel": dominant, "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": dom["frac"], "traffic": None, "launches": dom["launches"],
+                    "frac": dom["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                    "traffic_source": source,
+                    "algorithmic_bytes_per_launch": (sum(dom_bytes) / len(dom_bytes)) if dom_bytes else None,
+                    "launches": dom["launches"],
                     "avg_launch_ms": dom["avg_launch_ms"], "flops_per_launch": dom["flops_per_launch"],
                     "time_share_of_step": dom["time_share_of_step"], "other_kernels": summary}
             for tag, (n, by, sec) in kernels.items():
@@ -176,8 +204,11 @@ def main():
                         "time_share_of_step": round(sec / elapsed, 3)}
             conv_flops = sum(k[1] for t, k in kernels.items() if not t.startswith("hbm:"))
             conv_secs = sum(k[2] for t, k in kernels.items() if not t.startswith("hbm:"))
-            roof["all_conv_mfma_util"] = round(conv_flops / conv_secs / 1e12 / peak, 4)
-            roof["all_conv_time_share_of_step"] = round(conv_secs / elapsed, 3)
+            if args.all_kernel_timing:
+                roof["all_conv_mfma_util"] = round(conv_flops / conv_secs / 1e12 / peak, 4)
+                roof["all_conv_time_share_of_step"] = round(conv_secs / elapsed, 3)
+            else:
+                roof["other_kernels_note"] = "run with --all-kernel-timing for the other kernel groups"
         if args.per_shape:
             for (tag, shape), (n, fl, sec) in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:args.per_shape_top]:
                 print("%-12s %-34s calls %4d  %8.3f ms/step  %7.1f %s" % (tag, shape, n, sec / args.steps * 1e3, fl / sec / 1e12,

@@ -273,6 +273,7 @@ class PackedWeights:
 # bracketed by two events recorded on the stream it is launched on, together with its algorithmic FLOPs
 # (tags starting with "hbm:" carry algorithmic bytes instead).
 kernel_timings = None
+kernel_timing_tags = None       # optional set of tags: only those launches are bracketed (each event costs about a microsecond)
 use_tile_kernel = True          # False forces the generic implicit-GEMM kernel (A/B comparisons, tests)
 
 
@@ -284,7 +285,7 @@ class _Timed:
         self.shape = None if d is None else (d.n, d.h, d.w, d.cin, d.cout, d.kh, d.stride)
 
     def __enter__(self):
-        if kernel_timings is not None:
+        if kernel_timings is not None and (kernel_timing_tags is None or self.tag in kernel_timing_tags):
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record(torch.cuda.current_stream())
         return self
