@@ -723,25 +723,34 @@ def test_inference_folds_batchnorm_into_the_convolution(pkg, oracle):
     assert rel_l2(fused, unfused) < 1e-2
 
 
-def test_seg_model_ragged_size_matches_oracle(pkg, oracle):
+@pytest.mark.parametrize("base_c, dtype", [(8, torch.float32), (32, torch.float32), (32, torch.bfloat16)])
+def test_seg_model_ragged_size_matches_oracle(pkg, oracle, base_c, dtype):
     """36 x 52 input: level 3 is 9 x 13, so that Up block pads (unfused path) while the others write the skip tensor
-    and the transposed convolution straight into the concatenated tensor."""
+    and the transposed convolution straight into the concatenated tensor.  base_c 32 in bf16 puts the tiled 3x3 kernels
+    (forward, backward-data, backward-weight) on 36x52 ... 2x3 images: every tile is partial."""
     torch.manual_seed(0)
-    m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 8).set_compute_dtype(torch.float32).to(DEV).train()
-    ref = oracle.UResNetNewEUCB(19, 3, 8).train()
+    m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, base_c).set_compute_dtype(dtype).to(DEV).train()
+    ref = oracle.UResNetNewEUCB(19, 3, base_c).train()
     ref.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 3, 36, 52, generator=g)
     tgt = torch.randint(0, 19, (2, 36, 52), generator=g)
     tgt[torch.rand(tgt.shape, generator=g) < 0.1] = 255
-    out = m(x.to(DEV))
-    loss = pkg.train.compute_loss(out, tgt.to(DEV))
-    loss.backward()
+    pkg.ops.kernel_timings = []
+    try:
+        out = m(x.to(DEV))
+        loss = pkg.train.compute_loss(out, tgt.to(DEV))
+        loss.backward()
+    finally:
+        tags, pkg.ops.kernel_timings = set(t[0] for t in pkg.ops.kernel_timings), None
+    if dtype == torch.bfloat16:
+        assert {"tile_fwd", "tile_dgrad", "tile_wgrad"} <= tags
     ro = ref(x)
     rl = torch.nn.functional.cross_entropy(ro, tgt, ignore_index=255)
     rl.backward()
-    assert rel_l2(host(pkg, out), ro.detach()) < 1e-4
-    assert abs(loss.item() - rl.item()) < 1e-5 * abs(rl.item())
+    exact = dtype == torch.float32
+    assert rel_l2(host(pkg, out), ro.detach()) < (1e-4 if exact else 6e-2)
+    assert abs(loss.item() - rl.item()) < (1e-5 if exact else 3e-2) * abs(rl.item())
     errs = []
     rp = dict(ref.named_parameters())
     big = max(p.grad.norm().item() for p in rp.values() if p.grad is not None)
@@ -752,4 +761,9 @@ def test_seg_model_ragged_size_matches_oracle(pkg, oracle):
         nrm = rp[k].grad.double().norm().item()
         if nrm > 1e-5 * big:
             errs.append(abs(p.grad.double().norm().item() - nrm) / nrm)
-    assert np.median(errs) < 1e-4 and max(errs) < 3e-2, (np.median(errs), max(errs))
+    if exact:
+        assert np.median(errs) < 1e-4 and max(errs) < 3e-2, (np.median(errs), max(errs))
+    else:
+        # bf16 storage of every activation: gradient norms drift by percents through 40 layers (the reference's own
+        # bf16-autocast run drifts 0.3-0.46 on gradients); the median pins the bulk, NaN/garbage would fail both
+        assert np.median(errs) < 5e-2 and max(errs) < 0.5, (np.median(errs), max(errs))
