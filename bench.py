@@ -101,6 +101,8 @@ def main():
     uresnet_amd._lib.load()
     if os.environ.get("URESNET_BATCH_PACK") == "0":          # A/B switches of two fusions
         ops.batch_repack = False
+    if os.environ.get("URESNET_PW") == "0":
+        ops.use_pw_kernel = False
     if os.environ.get("URESNET_POOL_SKIP") == "0":
         uresnet_amd.modules._blocks.fuse_pool_skip = False
     if os.environ.get("URESNET_RES_GRAD") == "0":
@@ -164,7 +166,7 @@ def main():
         if kernels:
             groups = {
                 "conv3x3_tile_kernel (3x3 s1 p1 forward + backward-data launches)": ("tile_fwd", "tile_dgrad"),
-                "conv_igemm_kernel (generic implicit GEMM: stem, 1x1, ConvT, skinny layers)": ("igemm_fwd", "igemm_dgrad"),
+                "conv_igemm_kernel (generic implicit GEMM: stem, 1x1, ConvT, skinny layers)": ("igemm_fwd", "igemm_dgrad", "pw_fwd", "pw_dgrad"),
                 "wgrad3x3_tile_kernel (3x3 s1 p1 backward-weight + slab reduce)": ("tile_wgrad",),
                 "conv_wgrad_kernel (generic backward-weight + slab reduce)": ("wgrad",),
             }

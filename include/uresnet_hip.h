@@ -74,6 +74,18 @@ size_t ur_conv2d_wgrad_workspace(const ur_conv_desc* d);
 int ur_conv2d_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
                     const ur_conv_desc* d, ur_stream_t s);
 
+/* ---------------------------------------------------------------- 1x1 / stride 1, bf16: streaming kernel
+ * Same results as ur_conv2d_fwd (without statistics) / ur_conv2d_dgrad for the pointwise layers that are bound by
+ * HBM, not by arithmetic (EUCB projection S/C:53-55, segmentation head S/C:127-133 and their gradients).  The
+ * weight is the fp32 parameter itself, [w_cout][w_cin] (no packing step); the tensors may carry more channels than
+ * the weight (zero channel padding up to a multiple of 8) and may be channel windows (in_ld / out_ld).
+ * Needs 8 | reduced channels and pitch; ur_conv1x1_pw_supported tells whether the register budget covers the shape. */
+int ur_conv1x1_pw_supported(const ur_conv_desc* d, int dgrad);
+int ur_conv1x1_pw_fwd(const void* x, const float* w, int w_cout, int w_cin, const float* bias, void* y,
+                      const ur_conv_desc* d, ur_stream_t s);
+int ur_conv1x1_pw_dgrad(const void* dy, const float* w, int w_cout, int w_cin, void* dx, const ur_conv_desc* d,
+                        ur_stream_t s);
+
 /* ---------------------------------------------------------------- 3x3 / stride 1 / pad 1, bf16: LDS-tiled kernel
  * Same contract as ur_conv2d_fwd / ur_conv2d_dgrad for the layers that carry ~94 % of the FLOPs
  * (S/C:94,97,140,143 with 64..1024 channels): needs 64 | produced channels, 32 | reduced channels.

@@ -129,6 +129,39 @@ def test_tiled_3x3_kernel_agrees_with_generic_kernel(pkg):
     assert rel_l2(res[True][3], res[False][3]) < 1e-5          # fp32 weight gradients from identical bf16 operands
 
 
+@pytest.mark.parametrize("shape", [(1, 80, 12, 20, 19, True), (3, 32, 9, 11, 16, True), (1, 64, 5, 7, 32, False),
+                                   (2, 24, 33, 31, 40, True), (2, 64, 8, 16, 128, False)])
+def test_pointwise_kernel_matches_generic_kernel_and_torch(pkg, shape):
+    """bf16 1x1 stride-1 convolutions without statistics take the streaming kernel (forward and backward-data): same
+    bf16 operands and fp32 accumulation as the generic kernel, so the two agree to summation order + one rounding."""
+    n, cin, h, w, cout, bias = shape
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = bf16_round(torch.randn(n, cin, h, w, generator=g))
+    wt = bf16_round(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    b = torch.randn(cout, generator=g) if bias else None
+    gy = bf16_round(torch.randn(n, cout, h, w, generator=g))
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b)
+    (yr * gy).sum().backward()
+    res = {}
+    for pw in (True, False):
+        pkg.ops.use_pw_kernel = pw
+        pkg.ops.kernel_timings = []
+        try:
+            xd, wd = x.to(DEV).requires_grad_(True), wt.to(DEV).requires_grad_(True)
+            bd = b.to(DEV) if bias else None
+            y, _ = pkg.ops.conv2d(pkg.ops.as_activation(xd, torch.bfloat16), wd, bd, pkg.ops.PackedWeights(), 1, 0)
+            (y.float() * pkg.ops.to_nhwc_raw(gy.to(DEV), torch.float32)).sum().backward()
+            res[pw] = (host(pkg, y), xd.grad.cpu(), wd.grad.cpu())
+        finally:
+            tags, pkg.ops.kernel_timings, pkg.ops.use_pw_kernel = set(t[0] for t in pkg.ops.kernel_timings), None, True
+        # 64 -> 128 channels is outside the streaming kernel's register budget: the generic kernel runs either way
+        assert ({"pw_fwd", "pw_dgrad"} <= tags) == (pw and cout <= 96)
+    assert rel_l2(res[True][0], res[False][0]) < 2e-3 and rel_l2(res[True][1], res[False][1]) < 2e-3
+    assert torch.equal(res[True][2], res[False][2])                 # backward-weight is the same kernel either way
+    assert rel_l2(res[True][0], yr) < 1e-2 and rel_l2(res[True][1], xr.grad) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 64, 8, 16, 32), (1, 128, 5, 7, 64), (2, 16, 4, 4, 8)])
 def test_conv_transpose2x2(pkg, shape, dtype):

@@ -275,6 +275,7 @@ class PackedWeights:
 kernel_timings = None
 kernel_timing_tags = None       # optional set of tags: only those launches are bracketed (each event costs about a microsecond)
 use_tile_kernel = True          # False forces the generic implicit-GEMM kernel (A/B comparisons, tests)
+use_pw_kernel = True            # False: 1x1 convolutions go through the generic kernel too
 
 
 class _Timed:
@@ -367,14 +368,21 @@ class _Conv2d(Function):
             if cin % 8:
                 x = _pad_channels(x, _pad8(cin))
                 d = _desc(x.shape, cout, kh, kw, stride, pad, x.dtype)
-            wp = packs.get(weight, d, _lib.PACK_FWD)
-            if want_stats:
-                rows = query("ur_conv2d_stats_rows", C.byref(d))
-                stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
             if win_ld:
                 d.out_ld = win_ld
-            with _Timed("igemm_fwd", _conv_flops(d), d):
-                call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
+            if (use_pw_kernel and not want_stats and weight.dtype == torch.float32 and weight.is_contiguous()
+                    and query("ur_conv1x1_pw_supported", C.byref(d), 0)):
+                # HBM-bound pointwise layer: streaming kernel, reads the fp32 parameter directly
+                with _Timed("pw_fwd", _conv_flops(d), d):
+                    call("ur_conv1x1_pw_fwd", x.data_ptr(), weight.data_ptr(), cout, cin, _p(bias), y.data_ptr(), C.byref(d),
+                         _stream())
+            else:
+                wp = packs.get(weight, d, _lib.PACK_FWD)
+                if want_stats:
+                    rows = query("ur_conv2d_stats_rows", C.byref(d))
+                    stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
+                with _Timed("igemm_fwd", _conv_flops(d), d):
+                    call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
         if win_ld and tile:                          # the tile kernel writes dense tensors only
             _copy_channels(y, 0, cout, out[0], 0)
             y = out[0]
@@ -429,6 +437,10 @@ class _Conv2d(Function):
                         dalias = None
                     else:
                         call("ur_conv3x3_tile_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+            elif (use_pw_kernel and weight.dtype == torch.float32 and weight.is_contiguous()
+                    and query("ur_conv1x1_pw_supported", C.byref(d), 1)):
+                with _Timed("pw_dgrad", _conv_flops(d), d):
+                    call("ur_conv1x1_pw_dgrad", dy.data_ptr(), weight.data_ptr(), cout, cin, dx.data_ptr(), C.byref(d), _stream())
             else:
                 wp = ctx.packs.get(weight, d, _lib.PACK_DGRAD)
                 with _Timed("igemm_dgrad", _conv_flops(d), d):
