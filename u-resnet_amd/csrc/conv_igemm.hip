@@ -89,7 +89,7 @@ __device__ __forceinline__ bool tap_source(const IgemmParams& p, int oy, int ox,
 // Three workgroups per CU for the 32/64-column tiles (168 registers): the layers that come here have 1-8 reduction
 // slices, so what hides the gather latency is the number of resident workgroups (measured: +18 % over two).
 template <typename T, int BN, bool VEC8, bool FAST>
-__global__ __launch_bounds__(NTHREADS, (BN <= 64 && sizeof(T) == 2) ? 3 : 1) void conv_igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(NTHREADS, (BN <= 64 && sizeof(T) == 2) ? 3 : (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kernel(IgemmParams p) {
     constexpr int PITCH = LdsPitch<T>::elems;
     constexpr int NT = BN / 32;
     __shared__ __attribute__((aligned(16))) T As[BM * PITCH];
@@ -489,11 +489,16 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_igemm(IgemmParams& p, hipStream_t st) {
-    // 128-column tiles need 256 VGPRs (one workgroup per CU, nothing to overlap its barriers with) and measured
-    // 10-25 % slower than 64-column tiles (three workgroups per CU; the extra column tiles re-read A from L2) on every
-    // wide layer of the network; URESNET_IGEMM_BN128=1 selects them for A/B runs
-    static const bool bn128 = [] { const char* e = getenv("URESNET_IGEMM_BN128"); return e && e[0] == '1'; }();
-    if (p.Ncols > 64 && bn128) return launch_igemm<T, 128>(p, st);
+    // 128-column tiles (246 registers, two workgroups per CU) halve the number of times a row tile's prologue, A gather
+    // and epilogue run, at the price of occupancy.  Measured per layer against 64-column tiles (three per CU): they win
+    // on GEMM-like layers with >= 4 reduction slices and enough tiles for >= 2 full rounds (transposed convolutions
+    // 128->64 ... 512->256: 207 -> 175, 139 -> 124, 104 -> 91 us; their backward-data 129 -> 111 us) and lose on short
+    // reductions (1x1 64->128: 82 -> 93 us) and small grids (1024->512 at 32x64: 95 -> 103 us).
+    // URESNET_IGEMM_BN128=1 / 0 forces / forbids them for A/B runs.
+    static const int bn128 = [] { const char* e = getenv("URESNET_IGEMM_BN128"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
+    const bool wide = sizeof(T) == 2 && p.Ncols >= 128 && p.Kred >= 128 &&
+                      (long long)ur_cdiv(p.M, BM) * ur_cdiv(p.Ncols, 128) >= 1024;
+    if (p.Ncols > 64 && (bn128 == 1 || (bn128 < 0 && wide))) return launch_igemm<T, 128>(p, st);
     if (p.Ncols > 32) return launch_igemm<T, 64>(p, st);
     return launch_igemm<T, 32>(p, st);
 }
