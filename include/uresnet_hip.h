@@ -88,7 +88,7 @@ int ur_conv1x1_pw_dgrad(const void* dy, const float* w, int w_cout, int w_cin, v
 
 /* ---------------------------------------------------------------- 3x3 / stride 1 / pad 1, bf16: LDS-tiled kernel
  * Same contract as ur_conv2d_fwd / ur_conv2d_dgrad for the layers that carry ~94 % of the FLOPs
- * (S/C:94,97,140,143 with 64..1024 channels): needs 64 | produced channels, 32 | reduced channels.
+ * (S/C:94,97,140,143 with 32..1024 channels): needs 32 | produced channels (computed in blocks of 64), 32 | reduced channels.
  * Weights are packed in MFMA-fragment order (dgrad != 0: tap-flipped and transposed). */
 int ur_conv3x3_tile_supported(const ur_conv_desc* d, int dgrad);
 size_t ur_conv3x3_tile_packed_elems(const ur_conv_desc* d);

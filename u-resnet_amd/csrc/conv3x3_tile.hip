@@ -2,7 +2,9 @@
 // Used for the forward pass and (with tap-flipped, transposed weights) for backward-data of the
 // layers that carry ~94 % of U-ResNet's FLOPs.
 //
-// Workgroup (4 waves) -> 4R x 32 output pixels x 64 output channels, R = 4 (R = 2 for small images).
+// Workgroup (4 waves) -> 4R x 32 output pixels x 64 output channels, R = 4 (R = 2 for small images).  A channel
+// count of 32 (mod 64) runs its last block half empty (zero weights, no stores): still twice as fast as the generic
+// kernel on the 32-channel layers.
 // The reduction runs over 16-channel slices of the input; two LDS stages alternate, one barrier per slice.
 // A stage holds
 //   * the (4R+2) x 34 pixel halo of the slice, 32 bytes per pixel; the two 16-byte pieces of a pixel are
@@ -62,7 +64,7 @@ struct TileParams {
     int N, H, W, Cin, Cout;
     int ld_in, ld_out;
     int tiles_x, tiles_y, tiles;     // spatial tiles per image row / column / total (N * ty * tx)
-    int nblocks;                     // Cout / 64
+    int nblocks;                     // ceil(Cout / 64): the last block of a 32 (mod 64) channel count is half empty
 };
 
 // ---- hand-issued LDS traffic ---------------------------------------------------------------------------
@@ -314,7 +316,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
     if constexpr (EPI == 2) {
         float sc[2], sh[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { sc[b] = p.scale[nb * BN + b * 32 + lx]; sh[b] = p.shift[nb * BN + b * 32 + lx]; }
+        for (int b = 0; b < 2; ++b) {
+            const int c = nb * BN + b * 32 + lx;
+            sc[b] = c < p.Cout ? p.scale[c] : 0.f; sh[b] = c < p.Cout ? p.shift[c] : 0.f;
+        }
         const bool relu_now = p.relu && !p.addend;
 #pragma unroll
         for (int a = 0; a < R; ++a)
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
         const int idx = lane + 64 * i;
         const int pxl = idx >> 3, piece = idx & 7;
         const int oy = ty0 + wave * R + (pxl >> 5), ox = tx0 + (pxl & 31);
-        if (!check || (oy < p.H && ox < p.W)) {
+        if (!check || (oy < p.H && ox < p.W && nb * BN + piece * 8 < p.Cout)) {
             const size_t pix = (size_t)(img * p.H + oy) * p.W + ox;
             bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ostage + pxl * OUT_PITCH + piece * 16);
             if constexpr (EPI != 0) {
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
             *reinterpret_cast<bf16x8_t*>(p.y + pix * p.ld_out + nb * BN + piece * 8) = v;
         }
     };
-    if (interior) {
+    if (interior && (nb + 1) * BN <= p.Cout) {
 #pragma unroll
         for (int i = 0; i < R * 4; ++i) store_piece(i, false);
     } else {
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
     }
     if (EPI == 0 && p.stats) {
         __syncthreads();
-        if (tid < BN) {
+        if (tid < BN && nb * BN + tid < p.Cout) {
             float* o = p.stats + ((size_t)tile * p.Cout + nb * BN + tid) * 2;
             o[0] = red[tid * 2] + red[(BN + tid) * 2] + red[(2 * BN + tid) * 2] + red[(3 * BN + tid) * 2];
             o[1] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1] + red[(2 * BN + tid) * 2 + 1] + red[(3 * BN + tid) * 2 + 1];
@@ -419,18 +424,18 @@ __device__ __forceinline__ void pack_tile_weights_body(const float* __restrict__
     const int rows = dgrad ? cin : cout;      // channels produced by the kernel
     const int red = dgrad ? cout : cin;       // channels reduced over
     const int chunks = red / KC;
-    const int nblocks = (rows / BN) * chunks;
+    const int nblocks = ((rows + BN - 1) / BN) * chunks;       // a last block of 32 channels is padded with zero weights
     for (int blk = first; blk < nblocks; blk += step) {
         const int nb = blk / chunks, chunk = blk - nb * chunks;
         if (!dgrad) {
             for (int i = threadIdx.x; i < PACK_BLOCK; i += blockDim.x) {
                 const int n = i / (KC * 9), rem = i - n * (KC * 9);
-                tile[i] = w[((size_t)(nb * BN + n) * cin + chunk * KC) * 9 + rem];
+                tile[i] = nb * BN + n < rows ? w[((size_t)(nb * BN + n) * cin + chunk * KC) * 9 + rem] : 0.f;
             }
         } else {
             for (int i = threadIdx.x; i < PACK_BLOCK; i += blockDim.x) {
                 const int k = i / (BN * 9), rem = i - k * (BN * 9);
-                tile[i] = w[((size_t)(chunk * KC + k) * cin + nb * BN) * 9 + rem];
+                tile[i] = nb * BN + rem / 9 < rows ? w[((size_t)(chunk * KC + k) * cin + nb * BN) * 9 + rem] : 0.f;
             }
         }
         __syncthreads();
@@ -467,8 +472,8 @@ int check(const ur_conv_desc* d, bool dgrad) {
     UR_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w,
                "conv3x3_tile: 3x3 stride 1 pad 1 only");
     const int rows = dgrad ? d->cin : d->cout, red = dgrad ? d->cout : d->cin;
-    UR_REQUIRE(rows % BN == 0 && red % (2 * KC) == 0, "conv3x3_tile: needs %d | produced channels and %d | reduced channels",
-               BN, 2 * KC);
+    UR_REQUIRE(rows % 32 == 0 && red % (2 * KC) == 0, "conv3x3_tile: needs 32 | produced channels and %d | reduced channels",
+               2 * KC);
     UR_REQUIRE(d->in_ld % 8 == 0 && d->out_ld % 8 == 0, "conv3x3_tile: pitches must be multiples of 8");
     UR_REQUIRE((long long)d->n * d->h * d->w * (d->in_ld > d->out_ld ? d->in_ld : d->out_ld) < (1LL << 31),
                "conv3x3_tile: tensor exceeds 2^31 elements");
@@ -482,7 +487,7 @@ int check(const ur_conv_desc* d, bool dgrad) {
 int pick_rows(const ur_conv_desc* d, bool dgrad) {
     static const int forced = [] { const char* e = getenv("URESNET_TILE_ROWS"); return e ? atoi(e) : 0; }();
     if (forced == 2 || forced == 4) return forced;
-    const long long wgs4 = (long long)d->n * ur_cdiv(d->h, 16) * ur_cdiv(d->w, TW) * ((dgrad ? d->cin : d->cout) / BN);
+    const long long wgs4 = (long long)d->n * ur_cdiv(d->h, 16) * ur_cdiv(d->w, TW) * ur_cdiv(dgrad ? d->cin : d->cout, BN);
     return (wgs4 >= 1024 || wgs4 % 512 == 0) ? 4 : 2;
 }
 
@@ -500,7 +505,7 @@ int launch(const void* src, const void* wpk, void* dst, float* stats, const ur_c
     p.ld_in = dgrad ? d->out_ld : d->in_ld; p.ld_out = dgrad ? d->in_ld : d->out_ld;
     p.tiles_x = ur_cdiv(d->w, TW); p.tiles_y = ur_cdiv(d->h, TH);
     p.tiles = d->n * p.tiles_x * p.tiles_y;
-    p.nblocks = p.Cout / BN;
+    p.nblocks = ur_cdiv(p.Cout, BN);
     const int grid = ((p.tiles + 7) / 8 * 8) * p.nblocks;
     const int epi = scale ? 2 : (addend ? 1 : 0);
 #define UR_TILE_LAUNCH(RR, EE) hipLaunchKernelGGL((conv3x3_tile_kernel<RR, EE>), dim3(grid), dim3(NTHREADS), 0, st, p)
@@ -518,13 +523,16 @@ int ur_conv3x3_tile_supported(const ur_conv_desc* d, int dgrad) {
     if (!d || d->dtype != UR_BF16) return 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w)) return 0;
     const int rows = dgrad ? d->cin : d->cout, red = dgrad ? d->cout : d->cin;
-    if (rows % BN != 0 || red % (2 * KC) != 0 || d->in_ld % 8 != 0 || d->out_ld % 8 != 0) return 0;
+    if (rows % 32 != 0 || red % (2 * KC) != 0 || d->in_ld % 8 != 0 || d->out_ld % 8 != 0) return 0;
     if ((long long)d->n * d->h * d->w * (d->in_ld > d->out_ld ? d->in_ld : d->out_ld) >= (1LL << 31)) return 0;
     if ((long long)d->w * (d->in_ld > d->out_ld ? d->in_ld : d->out_ld) >= (1LL << 24)) return 0;
     return 1;
 }
 
-size_t ur_conv3x3_tile_packed_elems(const ur_conv_desc* d) { return d ? (size_t)d->cin * d->cout * 9 : 0; }
+// either direction: the produced channels are padded to a multiple of 64
+size_t ur_conv3x3_tile_packed_elems(const ur_conv_desc* d) {
+    return d ? (size_t)ur_cdiv(d->cin, BN) * BN * ur_cdiv(d->cout, BN) * BN * 9 : 0;
+}
 
 int ur_conv3x3_tile_pack_weight(const float* w, void* packed, const ur_conv_desc* d, int dgrad, ur_stream_t s) {
     if (int e = check(d, dgrad != 0)) return e;
