@@ -12,6 +12,7 @@
 // transposing LDS read ds_read_b64_tr_b16; fp32 uses v_mfma_f32_32x32x2_f32, whose one-k-per
 // -lane operands are plain row reads of that layout.
 #include "ur_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -281,7 +282,11 @@ WgradPlan plan_for(int O, int Kred, long long P) {
     pl.ntiles = ur_cdiv(Kred, TN);
     long long stages = (P + BK - 1) / BK;
     long long tiles = (long long)pl.mtiles * pl.ntiles;
-    long long want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU in total
+    // One resident round: the vector-loader instantiations hold three workgroups per CU (156 registers, 40 KiB of
+    // LDS), so 768 equal shares finish together; 1024 left a quarter-filled second round (1.54 -> 1.32 ms per step
+    // over the network's eleven layers of this kind).  URESNET_WGRAD_WGS overrides for A/B runs.
+    static const int total = [] { const char* e = getenv("URESNET_WGRAD_WGS"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+    long long want = (total + tiles - 1) / tiles;
     if (want > stages) want = stages;
     if (want < 1) want = 1;
     pl.stages_per_split = (int)((stages + want - 1) / want);
