@@ -523,6 +523,34 @@ def test_temp_variant_fp32_matches_reference(pkg, name, cls):
     assert np.allclose(losses, rec["losses"], rtol=2e-3), (losses, rec["losses"])
 
 
+def test_graphed_sgd_step_replays_the_eager_step_bit_exactly(pkg):
+    """A training step captured as a HIP graph (train.GraphedStep) and replayed on new batches gives the same losses
+    as the eager step from the same state: same kernels, same order, nothing data-dependent on the host."""
+    M, train = pkg.modules.U_ResNet_CIFAR, pkg.train
+
+    def build():
+        torch.manual_seed(0)
+        m = M.UResNet4_No_SU(10, 3, scale=3).set_compute_dtype(torch.bfloat16).to(DEV).train()
+        return m, train.SGD(m.parameters(), lr=0.01)
+
+    g = torch.Generator().manual_seed(1234)
+    xs = [torch.randn(16, 3, 32, 32, generator=g).to(DEV) for _ in range(4)]
+    ys = [torch.randint(0, 10, (16,), generator=g).to(DEV) for _ in range(4)]
+    m, opt = build()
+    step = train.GraphedStep(train.cls_train_step, m, opt, xs[0], ys[0], warmup=3)
+    ref_m, ref_opt = build()
+    for _ in range(step.warmup_steps):                       # the warm-up steps ran for real, the capture did not
+        train.cls_train_step(ref_m, ref_opt, xs[0], ys[0])
+    got = [step(x, y)[0].item() for x, y in zip(xs, ys)]
+    want = [train.cls_train_step(ref_m, ref_opt, x, y)[0].item() for x, y in zip(xs, ys)]
+    assert got == want
+    for (k, a), b in zip(m.state_dict().items(), ref_m.state_dict().values()):
+        assert torch.equal(a, b), k
+    with pytest.raises(NotImplementedError):
+        m2 = M.UResNet4_No_SU(10, 3, scale=3).set_compute_dtype(torch.bfloat16).to(DEV).train()
+        train.GraphedStep(train.cls_train_step, m2, train.Adam(m2.parameters(), lr=1e-4), xs[0], ys[0], warmup=1)
+
+
 # ----------------------------------------------------------------------------- fused concatenation paths
 def test_channel_window_ops_are_bit_exact(pkg):
     """BatchNorm+ReLU into a channel window, max-pool from a window, ConvTranspose into a window == the dense ops."""

@@ -217,6 +217,8 @@ def _repack_stale_tile_images(device):
     if not rows:
         return
     if _tile_table[0] != rows:
+        if torch.cuda.is_current_stream_capturing():
+            return                     # a synchronous upload cannot be captured: the caller packs its own image instead
         _tile_table[0] = rows
         _tile_table[1] = torch.tensor(rows, dtype=torch.int64).to(device)
     call("ur_conv3x3_tile_pack_weights_multi", _tile_table[1].data_ptr(), len(rows), max(r[2] * r[3] * 9 for r in rows),

@@ -117,6 +117,7 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._table_key = None
         self._table = None
+        self._pin = None
         self.grad_scale = 1.0
 
     def _gather(self, group):
@@ -133,9 +134,14 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
     def _pointer_table(self, rows, sizes, device):
         key = tuple(v for r in rows for v in r)
         if key != self._table_key:
-            flat = torch.tensor([v for r in rows for v in r], dtype=torch.int64)
-            sz = torch.tensor(sizes, dtype=torch.int64)
-            self._table = (flat.to(device, non_blocking=False), sz.to(device, non_blocking=False), max(sizes))
+            # pinned staging (allocated once, outside any capture) + asynchronous copies: legal under HIP graph capture,
+            # where the copy becomes a graph node that re-reads the staging buffer at every replay
+            if self._pin is None or self._pin[0].numel() != len(key) or self._pin[1].numel() != len(sizes):
+                self._pin = (torch.empty(len(key), dtype=torch.int64).pin_memory(),
+                             torch.empty(len(sizes), dtype=torch.int64).pin_memory())
+            self._pin[0].copy_(torch.tensor(key, dtype=torch.int64))
+            self._pin[1].copy_(torch.tensor(sizes, dtype=torch.int64))
+            self._table = (self._pin[0].to(device, non_blocking=True), self._pin[1].to(device, non_blocking=True), max(sizes))
             self._table_key = key
         return self._table
 
@@ -188,6 +194,9 @@ class Adam(_MultiTensorOptimizer):
                 rows.append((p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()))
                 sizes.append(p.numel())
             step = self.state[ps[0]]['step']
+            if torch.cuda.is_current_stream_capturing():
+                raise NotImplementedError("Adam: the step count enters the kernel as a host scalar (bias correction); "
+                                          "a captured graph would replay a stale one.  Capture SGD steps, or run Adam eagerly")
             table, sz, mx = self._pointer_table(rows, sizes, ps[0].device)
             b1, b2 = group['betas']
             _lib.call("ur_adam_multi", table.data_ptr(), sz.data_ptr(), len(ps), mx, group['lr'], b1, b2, group['eps'],
@@ -218,6 +227,37 @@ class SGD(_MultiTensorOptimizer):
                       self.grad_scale, ops._stream())
         ops.bump_weights_epoch()
         return loss
+
+
+class GraphedStep:
+    """One training step captured as a HIP graph and replayed: for small inputs the step is bound by the few hundred
+    host-side launches, not by the GPU (CIFAR-shaped batch: 9 ms eager).  `step_fn(model, optimizer, *inputs)` is one of
+    the *_train_step functions; inputs are copied into static buffers before each replay, the returned loss / outputs
+    are static tensors that the next replay overwrites.  Plain-SGD optimisers only (see Adam.step); shapes are fixed at
+    construction; BatchNorm running statistics and counters advance on the device as in eager mode."""
+
+    def __init__(self, step_fn, model, optimizer, *example_inputs, warmup=3):
+        import gc
+        gc.collect()                                # dead models drop out of the shared weight-image table now, not mid-capture
+        self._static = [t.clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                 # allocator pools, weight images and pointer tables reach steady state
+                step_fn(model, optimizer, *self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self._out = step_fn(model, optimizer, *self._static)
+        self.warmup_steps = warmup
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self._static, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self._out
 
 
 def seg_train_step(model, optimizer, images, targets, count_hook=None, grad_hook=None):
