@@ -134,14 +134,23 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
     def _pointer_table(self, rows, sizes, device):
         key = tuple(v for r in rows for v in r)
         if key != self._table_key:
-            # pinned staging (allocated once, outside any capture) + asynchronous copies: legal under HIP graph capture,
-            # where the copy becomes a graph node that re-reads the staging buffer at every replay
-            if self._pin is None or self._pin[0].numel() != len(key) or self._pin[1].numel() != len(sizes):
-                self._pin = (torch.empty(len(key), dtype=torch.int64).pin_memory(),
-                             torch.empty(len(sizes), dtype=torch.int64).pin_memory())
-            self._pin[0].copy_(torch.tensor(key, dtype=torch.int64))
-            self._pin[1].copy_(torch.tensor(sizes, dtype=torch.int64))
-            self._table = (self._pin[0].to(device, non_blocking=True), self._pin[1].to(device, non_blocking=True), max(sizes))
+            flat, sz = torch.tensor(key, dtype=torch.int64), torch.tensor(sizes, dtype=torch.int64)
+            fits = self._pin is not None and self._pin[0].numel() == len(key) and self._pin[1].numel() == len(sizes)
+            if torch.cuda.is_current_stream_capturing():
+                # Under HIP graph capture the upload must be an asynchronous copy from pinned memory (it becomes a graph
+                # node that re-reads the staging buffer at every replay); the buffer was allocated by an eager step.
+                if not fits:
+                    raise RuntimeError("optimizer: run at least one eager step with the same parameters before capturing")
+                self._pin[0].copy_(flat)
+                self._pin[1].copy_(sz)
+                self._table = (self._pin[0].to(device, non_blocking=True), self._pin[1].to(device, non_blocking=True), max(sizes))
+            else:
+                # eager: a blocking copy (the host may run a whole step ahead of the GPU, so a staging buffer that the next
+                # rebuild overwrites must not be read asynchronously); keep pinned staging ready for a later capture
+                if not fits:
+                    self._pin = (torch.empty(len(key), dtype=torch.int64).pin_memory(),
+                                 torch.empty(len(sizes), dtype=torch.int64).pin_memory())
+                self._table = (flat.to(device), sz.to(device), max(sizes))
             self._table_key = key
         return self._table
 
