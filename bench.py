@@ -216,7 +216,7 @@ def main():
                 print("%-12s %-34s calls %4d  %8.3f ms/step  %7.1f %s" % (tag, shape, n, sec / args.steps * 1e3, fl / sec / 1e12,
                                                                           "TB/s" if tag.startswith("hbm:") else "TF"), file=sys.stderr)
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the host baseline is reported on the single-GPU line only
             cpu = cpu_baseline(H, W)
         out = {
             "metric": "train images/sec (node) Cityscapes 512x1024 bf16 @1/2/4/8 GPU; conv MFMA util %",
