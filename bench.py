@@ -141,6 +141,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
+    host_elapsed = time.perf_counter() - t0          # launches enqueued; the GPU is still working
     fence()
     elapsed = time.perf_counter() - t0
     timings, ops.kernel_timings = ops.kernel_timings, None
@@ -230,7 +231,8 @@ def main():
                                    "UResNetNewEUCB(19,3,64) training step: forward + CE(ignore 255) + backward + Adam(1e-4)"
                                    % (H, W),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "bn": "per-replica batch statistics", "final_loss": round(final_loss, 5)},
+                       "bn": "per-replica batch statistics", "final_loss": round(final_loss, 5),
+                       "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3)},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -118,6 +118,8 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
         self._table_key = None
         self._table = None
         self._pin = None
+        self._ring = None
+        self._ring_next = 0
         self.grad_scale = 1.0
 
     def _gather(self, group):
@@ -145,12 +147,25 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
                 self._pin[1].copy_(sz)
                 self._table = (self._pin[0].to(device, non_blocking=True), self._pin[1].to(device, non_blocking=True), max(sizes))
             else:
-                # eager: a blocking copy (the host may run a whole step ahead of the GPU, so a staging buffer that the next
-                # rebuild overwrites must not be read asynchronously); keep pinned staging ready for a later capture
+                # Eager: gradient tensors are new allocations every step, so the table changes every step.  A blocking
+                # upload would drain the GPU once per step (the host waits for the whole backward pass, then the next
+                # forward starts from an empty queue).  Instead: asynchronous copies from a ring of pinned staging
+                # buffers; a slot is rewritten only after the event behind its last copy has completed (four steps
+                # later, so the wait never blocks in practice).
                 if not fits:
                     self._pin = (torch.empty(len(key), dtype=torch.int64).pin_memory(),
                                  torch.empty(len(sizes), dtype=torch.int64).pin_memory())
-                self._table = (flat.to(device), sz.to(device), max(sizes))
+                    self._ring = [(torch.empty(len(key), dtype=torch.int64).pin_memory(),
+                                   torch.empty(len(sizes), dtype=torch.int64).pin_memory(), torch.cuda.Event())
+                                  for _ in range(4)]
+                    self._ring_next = 0
+                pf, ps_, ev = self._ring[self._ring_next]
+                self._ring_next = (self._ring_next + 1) % len(self._ring)
+                ev.synchronize()
+                pf.copy_(flat)
+                ps_.copy_(sz)
+                self._table = (pf.to(device, non_blocking=True), ps_.to(device, non_blocking=True), max(sizes))
+                ev.record(torch.cuda.current_stream(device))
             self._table_key = key
         return self._table
 
