@@ -13,6 +13,9 @@ Tolerances (relative L2 unless noted):
                  gradient checks use a tight MEDIAN (1e-4) and a loose per-tensor bound (3e-2)
   bit-exact    : channel shuffle, concat / pad, max-pool, argmax and sigmoid masks
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -160,6 +163,18 @@ def test_pointwise_kernel_matches_generic_kernel_and_torch(pkg, shape):
     assert rel_l2(res[True][0], res[False][0]) < 2e-3 and rel_l2(res[True][1], res[False][1]) < 2e-3
     assert torch.equal(res[True][2], res[False][2])                 # backward-weight is the same kernel either way
     assert rel_l2(res[True][0], yr) < 1e-2 and rel_l2(res[True][1], xr.grad) < 1e-2
+
+
+def test_specialised_kernels_randomised_against_generic(pkg, monkeypatch):
+    """60 random shapes (ragged images, channel windows, 32-multiple and odd channel counts): the streaming 1x1 kernel
+    and the tiled 3x3 kernel against the generic implicit GEMM on identical bf16 operands (tools/stress_parity.py)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py")
+    spec = importlib.util.spec_from_file_location("stress_parity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["stress_parity.py", "60"])
+    mod.main()                                   # exits non-zero on the first mismatch
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
