@@ -1,4 +1,5 @@
-"""Randomised A/B of the specialised convolution kernels against the generic implicit GEMM (same bf16 operands):
+"""Randomised checks.  BatchNorm (+residual, ReLU, channel windows) against torch; and an A/B of the specialised
+   convolution kernels against the generic implicit GEMM (same bf16 operands):
    streaming 1x1 kernel (forward, backward-data, channel windows) and the tiled 3x3 kernel on 32-multiple channel counts
    and ragged image sizes.    python tools/stress_parity.py [cases]"""
 import os, random, sys, torch
@@ -29,8 +30,63 @@ def run(x, w, b, k, pad, gy, out_win):
     return ops.dense(y).detach().clone() if out_win is not None else y.detach(), xd.grad, wd.grad, extra
 
 
+def bn_cases(n_cases):
+    """BatchNorm + residual + ReLU forward/backward against torch.nn.BatchNorm2d in train mode: random channel counts
+    (also not multiples of 4 / 8), image sizes, storage types, residual inputs and channel-window outputs."""
+    from uresnet_amd import nn as hnn, _lib
+    rnd = random.Random(11)
+    worst = 0.0
+    for case in range(n_cases):
+        c = rnd.choice([3, 8, 16, 19, 24, 32, 40, 64, 80, 100, 128, 256, 520]); n = rnd.choice([1, 2, 4])
+        h = rnd.randint(1, 33); w = rnd.randint(1, 47)
+        dtype = rnd.choice([torch.float32, torch.bfloat16]); res = rnd.random() < 0.4
+        act = rnd.choice([_lib.ACT_RELU, _lib.ACT_NONE])
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+        r = torch.randn(n, c, h, w, generator=g) if res else None
+        gy = torch.randn(n, c, h, w, generator=g)
+        if dtype == torch.bfloat16:
+            x = x.bfloat16().float(); gy = gy.bfloat16().float(); r = r.bfloat16().float() if res else None
+        bn_t = torch.nn.BatchNorm2d(c)
+        with torch.no_grad():
+            bn_t.weight.uniform_(0.5, 1.5); bn_t.bias.uniform_(-0.3, 0.3)
+        xr = x.clone().requires_grad_(True); rr = r.clone().requires_grad_(True) if res else None
+        yr = bn_t(xr)
+        yr = yr + rr if res else yr
+        if act == _lib.ACT_RELU:
+            yr = torch.relu(yr)
+        (yr * gy).sum().backward()
+        bn = hnn.BatchNorm2d(c).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(bn_t.weight); bn.bias.copy_(bn_t.bias)
+        xd = x.to(dev).requires_grad_(True); rd = r.to(dev).requires_grad_(True) if res else None
+        xa = ops.as_activation(xd, dtype); ra = ops.as_activation(rd, dtype) if res else None
+        win = None
+        if c % 8 == 0 and rnd.random() < 0.4:
+            tot = c + 8 * rnd.randint(1, 4); off = 8 * rnd.randint(0, (tot - c) // 8)
+            buf = ops.empty_nhwc(n, tot, h, w, dtype, dev).fill_(5.0); win = ops.alias_window(buf, off, c)
+        z = ops.bn_act(xa, bn, residual=ra, act=act, out=win)
+        (z.float() * ops.to_nhwc_raw(gy.to(dev), torch.float32)).sum().backward()
+        if n * h * w < 4:
+            continue                     # degenerate statistics: the gradients cancel to round-off
+        tol = 2e-4 if dtype == torch.float32 else 2e-2
+        zz = ops.dense(z) if win is not None else z
+        errs = [rel(ops.to_nchw_raw(zz.detach(), torch.float32).cpu(), yr.detach()), rel(xd.grad.cpu(), xr.grad),
+                rel(bn.weight.grad.cpu(), bn_t.weight.grad), rel(bn.bias.grad.cpu(), bn_t.bias.grad),
+                rel(bn.running_var.cpu(), bn_t.running_var)]
+        if res:
+            errs.append(rel(rd.grad.cpu(), rr.grad))
+        worst = max(worst, max(errs) / tol)
+        if max(errs) > tol:
+            print("MISMATCH bn case %d: n=%d c=%d %dx%d %s residual=%s act=%d window=%s errs=%s" % (
+                case, n, c, h, w, dtype, res, act, win is not None, errs))
+            sys.exit(1)
+    print("bn stress OK: %d cases, worst error / tolerance %.3f" % (n_cases, worst))
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    bn_cases(n_cases)
     rnd = random.Random(7)
     worst = 0.0
     for case in range(n_cases):

@@ -681,7 +681,10 @@ class _BNAct(Function):
         else:
             call("ur_bn_eval_prepare", running_mean.data_ptr(), running_var.data_ptr(), c, eps, mean.data_ptr(),
                  invstd.data_ptr(), _stream())
-        if out is None:
+        # backward re-reads the activated tensor (densely) when a residual was added before the activation: that
+        # combination writes a dense tensor first and copies it into the window
+        via_dense = out is not None and act and residual is not None
+        if out is None or via_dense:
             z, z_ld = torch.empty_like(y, memory_format=CL), c
         else:                                        # (window,): a channel window of a wider tensor (alias_window)
             z = out[0]
@@ -695,6 +698,13 @@ class _BNAct(Function):
         # the ReLU mask is recomputed from y in backward unless a residual was added before the activation
         ctx.save_for_backward(y, z if (act and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.act, ctx.eval, ctx.has_res = act, not training, residual is not None
+        if via_dense:
+            if tuple(out[0].shape) != tuple(y.shape) or out[0].dtype != y.dtype or not _channel_pitch(out[0]):
+                raise RuntimeError("bn_act: `out` must be a channel window with y's shape and dtype")
+            n_, _, h_, w_ = y.shape
+            call("ur_copy_channels", z.data_ptr(), c, 0, h_, w_, out[0].data_ptr(), _channel_pitch(out[0]), 0, h_, w_, 0, 0,
+                 n_, c, _dt(z), _stream())
+            return out[0]
         return z
 
     @staticmethod
