@@ -4,6 +4,7 @@
 // thread mapping so a wave touches contiguous memory, 4-channel (8/16-byte) accesses when the
 // channel counts and pitches allow.
 #include "ur_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -357,8 +358,56 @@ __global__ void transpose_cast_kernel(const TS* __restrict__ src, TD* __restrict
     }
 }
 
+// Few planes (an image: R = 1..4 channel planes of S pixels) -> pixel-major.  The 32 x 32 tile above would be nine
+// tenths empty; here a thread takes 8 consecutive pixels: two 16-byte loads per plane, 8 R contiguous outputs
+// written as 16-byte pieces.  Needs S % 8 == 0 and 16-byte aligned tensors.
+template <typename TD, int R>
+__global__ __launch_bounds__(NT) void planes_to_pixels_kernel(const float* __restrict__ src, TD* __restrict__ dst, long long S,
+                                                              long long groups) {
+    constexpr int PIECES = 8 * R * (int)sizeof(TD) / 16;
+    for (long long gidx = blockIdx.x * (long long)NT + threadIdx.x; gidx < groups; gidx += (long long)gridDim.x * NT) {
+        const long long per_img = S / 8;
+        const long long b = gidx / per_img, s0 = (gidx - b * per_img) * 8;
+        const float* sp = src + b * R * S + s0;
+        float v[R][8];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float4 lo = *reinterpret_cast<const float4*>(sp + r * S), hi = *reinterpret_cast<const float4*>(sp + r * S + 4);
+            v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w;
+            v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
+        }
+        union { TD e[8 * R]; uint4 q[PIECES]; } o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) o.e[i * R + r] = ur_from_float<TD>(v[r][i]);
+        uint4* dp = reinterpret_cast<uint4*>(dst + (b * S + s0) * R);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) dp[i] = o.q[i];
+    }
+}
+
+template <typename TD>
+bool launch_planes(const void* src, void* dst, int B, int R, int S, hipStream_t st) {
+    if (R < 1 || R > 4 || S % 8 != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return false;
+    const long long groups = (long long)B * (S / 8);
+    const int grid = ur_grid_1d(groups, NT);
+    const float* s = (const float*)src;
+    TD* d = (TD*)dst;
+    switch (R) {
+        case 1: hipLaunchKernelGGL((planes_to_pixels_kernel<TD, 1>), dim3(grid), dim3(NT), 0, st, s, d, (long long)S, groups); break;
+        case 2: hipLaunchKernelGGL((planes_to_pixels_kernel<TD, 2>), dim3(grid), dim3(NT), 0, st, s, d, (long long)S, groups); break;
+        case 3: hipLaunchKernelGGL((planes_to_pixels_kernel<TD, 3>), dim3(grid), dim3(NT), 0, st, s, d, (long long)S, groups); break;
+        default: hipLaunchKernelGGL((planes_to_pixels_kernel<TD, 4>), dim3(grid), dim3(NT), 0, st, s, d, (long long)S, groups); break;
+    }
+    return true;
+}
+
 template <typename TS, typename TD>
 int launch_transpose(const void* src, void* dst, int B, int R, int S, hipStream_t st) {
+    if constexpr (std::is_same<TS, float>::value) {
+        if (launch_planes<TD>(src, dst, B, R, S, st)) return ur_check_launch("planes_to_pixels");
+    }
     const long long tiles = (long long)ur_cdiv(S, 32) * ur_cdiv(R, 32);
     if (tiles >= (1LL << 31) || B > 65535) { ur_set_error("transpose: dimension too large"); return UR_ERR_INVALID; }
     dim3 grid((unsigned)tiles, B, 1);
