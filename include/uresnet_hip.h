@@ -212,6 +212,10 @@ int ur_avgpool_bwd(const void* dy, void* dx, int dtype, int n, int h, int w, int
 int ur_copy_channels(const void* src, int src_ld, int src_coff, int sh, int sw, void* dst, int dst_ld,
                      int dst_coff, int dh, int dw, int pad_t, int pad_l, int n, int c, int dtype,
                      ur_stream_t s);
+/* dst[r][0..c) = src[r][0..c), dst[r][c..dst_c) = 0 for dense rows: widens a 3-channel image or a 19-class gradient
+ * (S/C:94, S/C:132 backward) to the multiple of 8 channels the generic kernels gather.  dst_c * element size must be a
+ * multiple of 16, c * element size <= 128, both tensors 16-byte aligned. */
+int ur_pad_channels(const void* src, int c, void* dst, int dst_c, long long rows, int dtype, ur_stream_t s);
 /* general channel shuffle (S/C:6-15): out[.., j*groups + i] = x[.., i*(c/groups) + j] */
 int ur_channel_shuffle(const void* x, void* y, int dtype, long long rows, int c, int groups, ur_stream_t s);
 /* stand-alone activations of act_layer (S/C:17-34); backward takes the forward INPUT x */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ur_avgpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_avgpool_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_copy_channels": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ur_pad_channels": (_i, [_vp, _i, _vp, _i, _ll, _i, _vp]),
     "ur_channel_shuffle": (_i, [_vp, _vp, _i, _ll, _i, _i, _vp]),
     "ur_act_fwd": (_i, [_vp, _vp, _i, _ll, _i, _f, _vp]),
     "ur_act_bwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _f, _vp]),

@@ -275,6 +275,40 @@ __global__ __launch_bounds__(NT) void copy_channels_kernel(const T* __restrict__
     }
 }
 
+// Rows of C channels -> rows of OC >= C channels, zero filled (the generic kernels gather 8 channels per load, so a
+// 3-channel image or a 19-class gradient is widened to a multiple of 8 first).  A workgroup moves 256 rows: the
+// contiguous source span goes through LDS with 16-byte accesses, then every thread writes one widened row in 16-byte
+// pieces.  OC * sizeof(T) must be a multiple of 16, both tensors 16-byte aligned, C * sizeof(T) <= 128.
+template <typename T>
+__global__ __launch_bounds__(NT) void pad_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, long long rows, int C, int OC) {
+    __shared__ uint4 stage[NT * 128 / 16];
+    T* tile = reinterpret_cast<T*>(stage);
+    constexpr int EV = 16 / (int)sizeof(T);
+    const long long nblocks = (rows + NT - 1) / NT;
+    for (long long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const long long r0 = b * NT;
+        const int nrows = (int)((rows - r0) < NT ? (rows - r0) : NT);
+        if (nrows == NT) {
+            const uint4* sp = reinterpret_cast<const uint4*>(src + r0 * C);
+            for (int i = threadIdx.x; i < NT * C / EV; i += NT) stage[i] = sp[i];
+        } else {
+            for (int i = threadIdx.x; i < nrows * C; i += NT) tile[i] = src[r0 * C + i];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nrows) {
+            const T* row = tile + threadIdx.x * C;
+            uint4* out = reinterpret_cast<uint4*>(dst + (r0 + threadIdx.x) * OC);
+            for (int q = 0; q < OC / EV; ++q) {
+                union { T e[EV]; uint4 v; } o;
+#pragma unroll
+                for (int k = 0; k < EV; ++k) o.e[k] = q * EV + k < C ? row[q * EV + k] : ur_from_float<T>(0.f);
+                out[q] = o.v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void channel_shuffle_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows,
                                                              int C, int groups) {
@@ -552,6 +586,17 @@ int ur_copy_channels(const void* src, int src_ld, int src_coff, int sh, int sw, 
     UR_REQUIRE_32BIT(total, "copy_channels");
     SPATIAL_LAUNCH(copy_channels_kernel, total, (const T*)sp, src_ld, sh, sw, (T*)dp, dst_ld, dh, dw, pad_t, pad_l, n, c);
     return ur_check_launch("copy_channels");
+}
+
+int ur_pad_channels(const void* src, int c, void* dst, int dst_c, long long rows, int dtype, ur_stream_t s) {
+    UR_REQUIRE(src && dst && rows > 0 && c > 0 && dst_c >= c, "pad_channels: bad arguments");
+    const int es = esize(dtype);
+    UR_REQUIRE((dst_c * es) % 16 == 0 && c * es <= 128 && al(src, 16) && al(dst, 16),
+               "pad_channels: needs 16-byte aligned tensors, output rows of whole 16-byte pieces and input rows of at most 128 bytes");
+    const int grid = ur_grid_1d(rows, NT, 256 * 8);
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pad_rows_kernel<T>), dim3(grid), dim3(NT), 0, (hipStream_t)s, (const T*)src,
+                                                (T*)dst, rows, c, dst_c));
+    return ur_check_launch("pad_channels");
 }
 
 int ur_channel_shuffle(const void* x, void* y, int dtype, long long rows, int c, int groups, ur_stream_t s) {

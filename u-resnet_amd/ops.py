@@ -327,6 +327,11 @@ def _pad_channels(x, cpad):
     8 channels per 16/32-byte load only when the channel count is a multiple of 8; a 3-channel image or a
     19-class gradient would otherwise be gathered element by element."""
     n, c, h, w = x.shape
+    es = x.element_size()
+    if _is_nhwc_dense(x) and (cpad * es) % 16 == 0 and c * es <= 128 and x.data_ptr() % 16 == 0:
+        xp = empty_nhwc(n, cpad, h, w, x.dtype, x.device)          # one pass: rows widened and zero filled together
+        call("ur_pad_channels", x.data_ptr(), c, xp.data_ptr(), cpad, n * h * w, _dt(x), _stream())
+        return xp
     xp = empty_nhwc(n, cpad, h, w, x.dtype, x.device).zero_()
     call("ur_copy_channels", x.data_ptr(), c, 0, h, w, xp.data_ptr(), cpad, 0, h, w, 0, 0, n, c, _dt(x), _stream())
     return xp
