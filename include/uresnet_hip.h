@@ -94,9 +94,10 @@ int ur_conv3x3_tile_supported(const ur_conv_desc* d, int dgrad);
 size_t ur_conv3x3_tile_packed_elems(const ur_conv_desc* d);
 int ur_conv3x3_tile_pack_weight(const float* w, void* packed, const ur_conv_desc* d, int dgrad, ur_stream_t s);
 /* the same for many layers in one launch (after an optimiser step every layer's image is stale at once):
- * table = device array of `entries` rows {w, packed, cin, cout, dgrad}, five 64-bit words each;
- * max_elems = the largest cin * cout * 9 among them (sizes the grid) */
-int ur_conv3x3_tile_pack_weights_multi(const long long* table, int entries, long long max_elems, ur_stream_t s);
+ * table = device array of `entries` rows {w, packed, cin, cout, dgrad, first_block}, six 64-bit words each, where
+ * first_block = the sum of ur_conv3x3_tile_pack_blocks over the rows before it; total_blocks = that sum over all rows */
+long long ur_conv3x3_tile_pack_blocks(int cin, int cout, int dgrad);
+int ur_conv3x3_tile_pack_weights_multi(const long long* table, int entries, long long total_blocks, ur_stream_t s);
 int ur_conv3x3_tile_stats_rows(const ur_conv_desc* d);
 int ur_conv3x3_tile_fwd(const void* x, const void* w_packed, void* y, float* stats, const ur_conv_desc* d,
                         ur_stream_t s);

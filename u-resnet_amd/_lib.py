@@ -45,6 +45,7 @@ SIGNATURES = {
     "ur_conv3x3_tile_packed_elems": (_sz, [_dp]),
     "ur_conv3x3_tile_pack_weight": (_i, [_vp, _vp, _dp, _i, _vp]),
     "ur_conv3x3_tile_pack_weights_multi": (_i, [_vp, _i, _ll, _vp]),
+    "ur_conv3x3_tile_pack_blocks": (_ll, [_i, _i, _i]),
     "ur_conv3x3_tile_stats_rows": (_i, [_dp]),
     "ur_conv3x3_tile_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),

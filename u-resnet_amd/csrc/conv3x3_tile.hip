@@ -458,12 +458,20 @@ __global__ __launch_bounds__(256) void pack_tile_weights_kernel(const float* __r
     pack_tile_weights_body(w, dst, cin, cout, dgrad, blockIdx.x, gridDim.x, tile);
 }
 
-// Many layers in one launch: table[e] = {w, dst, cin, cout, dgrad} (64-bit words), workgroups (x, e) walk entry e
-__global__ __launch_bounds__(256) void pack_tile_weights_multi_kernel(const long long* __restrict__ table) {
+// Many layers in one launch: table[e] = {w, dst, cin, cout, dgrad, first block} (64-bit words).  One workgroup per
+// 64 x 16 x 9 block of any layer: the blocks of all layers form one list (a 1024 x 1024 layer has 1024 of them, a
+// 64 x 64 layer 4), so the launch is balanced whatever the mix; the workgroup finds its layer by bisection.
+__global__ __launch_bounds__(256) void pack_tile_weights_multi_kernel(const long long* __restrict__ table, int entries) {
     __shared__ float tile[PACK_BLOCK];
-    const long long* row = table + 5 * (long long)blockIdx.y;
+    const long long b = blockIdx.x;
+    int lo = 0, hi = entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[6 * (long long)mid + 5] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long long* row = table + 6 * (long long)lo;
     pack_tile_weights_body(reinterpret_cast<const float*>(row[0]), reinterpret_cast<bf16_t*>(row[1]), (int)row[2], (int)row[3],
-                           (int)row[4], blockIdx.x, gridDim.x, tile);
+                           (int)row[4], (int)(b - row[5]), 1 << 30, tile);
 }
 
 int check(const ur_conv_desc* d, bool dgrad) {
@@ -546,12 +554,17 @@ int ur_conv3x3_tile_pack_weight(const float* w, void* packed, const ur_conv_desc
     return ur_check_launch("pack_tile_weights");
 }
 
-int ur_conv3x3_tile_pack_weights_multi(const long long* table, int entries, long long max_elems, ur_stream_t s) {
-    UR_REQUIRE(table && entries > 0 && entries <= 65535 && max_elems > 0, "conv3x3_tile_pack_weights_multi: bad arguments");
-    // workgroups per entry sized for the largest one (one 64 x 16 x 9 block each); smaller entries finish early
-    hipLaunchKernelGGL(pack_tile_weights_multi_kernel, dim3(ur_grid_1d(max_elems, PACK_BLOCK, 512), entries), dim3(256), 0,
-                       (hipStream_t)s, table);
+int ur_conv3x3_tile_pack_weights_multi(const long long* table, int entries, long long total_blocks, ur_stream_t s) {
+    UR_REQUIRE(table && entries > 0 && total_blocks > 0 && total_blocks < (1LL << 31),
+               "conv3x3_tile_pack_weights_multi: bad arguments");
+    hipLaunchKernelGGL(pack_tile_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)s, table, entries);
     return ur_check_launch("pack_tile_weights_multi");
+}
+
+// blocks of one layer's image in one direction (the unit of the multi-layer launch)
+long long ur_conv3x3_tile_pack_blocks(int cin, int cout, int dgrad) {
+    const int rows = dgrad ? cin : cout, red = dgrad ? cout : cin;
+    return (long long)ur_cdiv(rows, BN) * (red / KC);
 }
 
 int ur_conv3x3_tile_stats_rows(const ur_conv_desc* d) {

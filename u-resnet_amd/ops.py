@@ -198,7 +198,7 @@ _tile_table = [None, None]  # (rows, device table) of the last batched repack
 def _repack_stale_tile_images(device):
     """After an optimiser step every cached tile-kernel weight image is stale at once: rebuild them all with one
     launch (in place, the images keep their storage) instead of one launch per layer and direction."""
-    rows, hits, live = [], [], []
+    rows, hits, live, nblocks = [], [], [], 0
     for ref, mode, wref in _tile_images:
         pw, w = ref(), wref()
         if pw is None or w is None:
@@ -211,7 +211,9 @@ def _repack_stale_tile_images(device):
         new_key = (w.data_ptr(), w._version, _weights_epoch) + key[3:]
         if key == new_key or key[0] != new_key[0]:
             continue
-        rows.append((w.data_ptr(), packed.data_ptr(), key[4], key[5], int(mode == "tile_dgrad")))
+        dg = int(mode == "tile_dgrad")
+        rows.append((w.data_ptr(), packed.data_ptr(), key[4], key[5], dg, nblocks))
+        nblocks += query("ur_conv3x3_tile_pack_blocks", key[4], key[5], dg)
         hits.append((pw, mode, new_key, packed))
     _tile_images[:] = live
     if not rows:
@@ -221,8 +223,7 @@ def _repack_stale_tile_images(device):
             return                     # a synchronous upload cannot be captured: the caller packs its own image instead
         _tile_table[0] = rows
         _tile_table[1] = torch.tensor(rows, dtype=torch.int64).to(device)
-    call("ur_conv3x3_tile_pack_weights_multi", _tile_table[1].data_ptr(), len(rows), max(r[2] * r[3] * 9 for r in rows),
-         _stream())
+    call("ur_conv3x3_tile_pack_weights_multi", _tile_table[1].data_ptr(), len(rows), nblocks, _stream())
     for pw, mode, new_key, packed in hits:
         pw._cache[mode] = (new_key, packed)
 
