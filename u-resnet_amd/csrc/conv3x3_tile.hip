@@ -419,6 +419,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
 // source is 64 runs of 144 floats (forward) or 16 runs of 576 floats (dgrad): read coalesced into LDS, written
 // back as 16-byte pieces in fragment order.
 constexpr int PACK_BLOCK = BN * KC * 9;
+constexpr int PACK_ROW = KC * 9 + 1;              // forward staging rows are 144 floats: one pad word makes the lane stride odd
+constexpr int PACK_TILE = BN * PACK_ROW;          // (an even stride of 144 words put 32 lanes on two LDS banks)
 __device__ __forceinline__ void pack_tile_weights_body(const float* __restrict__ w, bf16_t* __restrict__ dst, int cin, int cout,
                                                         int dgrad, int first, int step, float* tile) {
     const int rows = dgrad ? cin : cout;      // channels produced by the kernel
@@ -427,15 +429,27 @@ __device__ __forceinline__ void pack_tile_weights_body(const float* __restrict__
     const int nblocks = ((rows + BN - 1) / BN) * chunks;       // a last block of 32 channels is padded with zero weights
     for (int blk = first; blk < nblocks; blk += step) {
         const int nb = blk / chunks, chunk = blk - nb * chunks;
-        if (!dgrad) {
-            for (int i = threadIdx.x; i < PACK_BLOCK; i += blockDim.x) {
-                const int n = i / (KC * 9), rem = i - n * (KC * 9);
-                tile[i] = nb * BN + n < rows ? w[((size_t)(nb * BN + n) * cin + chunk * KC) * 9 + rem] : 0.f;
+        // 36 elements per thread, 12 loads in flight at a time (one load per loop trip left the copy latency-bound)
+        constexpr int U = 12;
+        static_assert(PACK_BLOCK % (256 * U) == 0, "the staging loop assumes 256 threads");
+        for (int base = threadIdx.x; base < PACK_BLOCK; base += 256 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * 256;
+                if (!dgrad) {
+                    const int n = i / (KC * 9), rem = i - n * (KC * 9);
+                    v[u] = nb * BN + n < rows ? w[((size_t)(nb * BN + n) * cin + chunk * KC) * 9 + rem] : 0.f;
+                } else {
+                    const int k = i / (BN * 9), rem = i - k * (BN * 9);
+                    v[u] = nb * BN + rem / 9 < rows ? w[((size_t)(chunk * KC + k) * cin + nb * BN) * 9 + rem] : 0.f;
+                }
             }
-        } else {
-            for (int i = threadIdx.x; i < PACK_BLOCK; i += blockDim.x) {
-                const int k = i / (BN * 9), rem = i - k * (BN * 9);
-                tile[i] = nb * BN + rem / 9 < rows ? w[((size_t)(chunk * KC + k) * cin + nb * BN) * 9 + rem] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * 256;
+                if (!dgrad) { const int n = i / (KC * 9); tile[n * PACK_ROW + (i - n * (KC * 9))] = v[u]; }
+                else tile[i] = v[u];
             }
         }
         __syncthreads();
@@ -445,7 +459,7 @@ __device__ __forceinline__ void pack_tile_weights_body(const float* __restrict__
             bf16x8_t o;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                o[j] = (bf16_t)(dgrad ? tile[(k0 + j) * (BN * 9) + n * 9 + (8 - tap)] : tile[n * (KC * 9) + (k0 + j) * 9 + tap]);
+                o[j] = (bf16_t)(dgrad ? tile[(k0 + j) * (BN * 9) + n * 9 + (8 - tap)] : tile[n * PACK_ROW + (k0 + j) * 9 + tap]);
             *reinterpret_cast<bf16x8_t*>(dst + ((size_t)blk * (PACK_BLOCK / 8) + pi) * 8) = o;
         }
         __syncthreads();
@@ -454,7 +468,7 @@ __device__ __forceinline__ void pack_tile_weights_body(const float* __restrict__
 
 __global__ __launch_bounds__(256) void pack_tile_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int cin,
                                                                 int cout, int dgrad) {
-    __shared__ float tile[PACK_BLOCK];
+    __shared__ float tile[PACK_TILE];
     pack_tile_weights_body(w, dst, cin, cout, dgrad, blockIdx.x, gridDim.x, tile);
 }
 
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(256) void pack_tile_weights_kernel(const float* __r
 // 64 x 16 x 9 block of any layer: the blocks of all layers form one list (a 1024 x 1024 layer has 1024 of them, a
 // 64 x 64 layer 4), so the launch is balanced whatever the mix; the workgroup finds its layer by bisection.
 __global__ __launch_bounds__(256) void pack_tile_weights_multi_kernel(const long long* __restrict__ table, int entries) {
-    __shared__ float tile[PACK_BLOCK];
+    __shared__ float tile[PACK_TILE];
     const long long b = blockIdx.x;
     int lo = 0, hi = entries - 1;
     while (lo < hi) {
