@@ -190,6 +190,42 @@ __global__ __launch_bounds__(NT) void upsample_bwd_kernel(const T* __restrict__ 
         float acc[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        if (scale == 2) {
+            // the 4 x 4 output pixels that can read this input pixel: all 16 loads issued before the first use (the
+            // generic loops below wait for each load in turn); same summation order, zero weights where they skip
+            float wy[4], wx[4]; int oys[4], oxs[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int oy = 2 * iy - 1 + a, ox = 2 * ix - 1 + a;
+                const bool vy = (unsigned)oy < (unsigned)OH, vx = (unsigned)ox < (unsigned)OW;
+                oys[a] = vy ? oy : 0; oxs[a] = vx ? ox : 0;
+                int i0, i1; float l0, l1;
+                bilin_src(oys[a], rscale, H, i0, i1, l0, l1);
+                wy[a] = vy ? (i0 == iy ? l0 : 0.f) + (i1 == iy ? l1 : 0.f) : 0.f;
+                bilin_src(oxs[a], rscale, W, i0, i1, l0, l1);
+                wx[a] = vx ? (i0 == ix ? l0 : 0.f) + (i1 == ix ? l1 : 0.f) : 0.f;
+            }
+            Pack<T, V> g[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) g[a][b].load(dy + (((long long)n * OH + oys[a]) * OW + oxs[b]) * C + cv * V);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float wgt = wy[a] * wx[b];
+                    if (wgt != 0.f) {
+#pragma unroll
+                        for (int k = 0; k < V; ++k) acc[k] += wy[a] * wx[b] * g[a][b].v[k];
+                    }
+                }
+            Pack<T, V> o2;
+#pragma unroll
+            for (int k = 0; k < V; ++k) o2.v[k] = acc[k];
+            o2.store(dx + (size_t)pix * C + cv * V);
+            continue;
+        }
         const int oy_lo = max(0, scale * (iy - 1)), oy_hi = min(OH, scale * (iy + 2));
         const int ox_lo = max(0, scale * (ix - 1)), ox_hi = min(OW, scale * (ix + 2));
         for (int oy = oy_lo; oy < oy_hi; ++oy) {
