@@ -175,6 +175,30 @@ __global__ __launch_bounds__(NT) void upsample_fwd_kernel(const T* __restrict__ 
     }
 }
 
+// One output row per blockIdx.y: the row's vertical taps are workgroup-uniform and the only per-thread division left
+// is by the channel-vector count (the flat kernel above spends more time in three 32-bit divisions per 16-byte store
+// than on memory).
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void upsample_fwd_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C,
+                                                               int scale, float rscale) {
+    const int OH = H * scale, OW = W * scale, CV = C / V;
+    const int e = blockIdx.x * NT + threadIdx.x;
+    if (e >= OW * CV) return;
+    const int row = blockIdx.y, n = row / OH, oy = row - n * OH;
+    const int ox = e / CV, cv = e - ox * CV;
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    bilin_src(oy, rscale, H, y0, y1, ly0, ly1);
+    bilin_src(ox, rscale, W, x0, x1, lx0, lx1);
+    const T* b = x + (long long)n * H * W * C + cv * V;
+    Pack<T, V> v00, v01, v10, v11, o;
+    v00.load(b + ((long long)y0 * W + x0) * C); v01.load(b + ((long long)y0 * W + x1) * C);
+    v10.load(b + ((long long)y1 * W + x0) * C); v11.load(b + ((long long)y1 * W + x1) * C);
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+        o.v[k] = ly0 * (lx0 * v00.v[k] + lx1 * v01.v[k]) + ly1 * (lx0 * v10.v[k] + lx1 * v11.v[k]);
+    o.store(y + ((size_t)row * OW + ox) * C + cv * V);
+}
+
 // gather form of the adjoint: each input pixel sums the output pixels that read it (fixed order, no atomics)
 template <typename T, int V>
 __global__ __launch_bounds__(NT) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
@@ -575,6 +599,16 @@ int ur_upsample_bilinear_fwd(const void* x, void* y, int dtype, int n, int h, in
     const long long total = (long long)n * h * scale * w * scale * c;
     UR_REQUIRE_32BIT(total, "upsample_fwd");
     const float rscale = (float)(1.0 / (double)scale);
+    if ((long long)n * h * scale <= 65535) {
+        const unsigned rows = (unsigned)(n * h * scale);
+        const int ow = w * scale;
+        UR_DISPATCH_DTYPE(dtype, {
+            if (vec8) hipLaunchKernelGGL((upsample_fwd_rows_kernel<T, 8>), dim3(ur_cdiv((long long)ow * (c / 8), NT), rows), dim3(NT), 0, (hipStream_t)s, (const T*)x, (T*)y, h, w, c, scale, rscale);
+            else if (vec) hipLaunchKernelGGL((upsample_fwd_rows_kernel<T, 4>), dim3(ur_cdiv((long long)ow * (c / 4), NT), rows), dim3(NT), 0, (hipStream_t)s, (const T*)x, (T*)y, h, w, c, scale, rscale);
+            else hipLaunchKernelGGL((upsample_fwd_rows_kernel<T, 1>), dim3(ur_cdiv((long long)ow * c, NT), rows), dim3(NT), 0, (hipStream_t)s, (const T*)x, (T*)y, h, w, c, scale, rscale);
+        });
+        return ur_check_launch("upsample_fwd");
+    }
     SPATIAL_LAUNCH(upsample_fwd_kernel, total, (const T*)x, (T*)y, n, h, w, c, scale, rscale);
     return ur_check_launch("upsample_fwd");
 }
