@@ -143,6 +143,11 @@ int ur_colsum(const void* x, int dtype, long long rows, int c, int ld, float* ou
  * groups=C/4, cpg=4).  Weights stay in PyTorch layout (C, cpg, 3, 3) fp32. */
 int ur_gconv3x3_fwd(const void* x, const float* w, void* y, int dtype, int n, int h, int w_, int c, int cpg,
                     ur_stream_t s);
+/* the same with BatchNorm partial sums from the kernel's epilogue (EUCB* stages, S/C:69-81: grouped conv -> BN):
+ * stats[ur_gconv3x3_stats_rows(...)][c][2]; rows == 0 means this shape has no such kernel (use ur_bn_stats) */
+int ur_gconv3x3_stats_rows(int dtype, int n, int h, int w_, int c, int cpg);
+int ur_gconv3x3_fwd_stats(const void* x, const float* w, void* y, float* stats, int dtype, int n, int h, int w_, int c, int cpg,
+                          ur_stream_t s);
 int ur_gconv3x3_dgrad(const void* dy, const float* w, void* dx, int dtype, int n, int h, int w_, int c, int cpg,
                       ur_stream_t s);
 size_t ur_gconv3x3_wgrad_workspace(int n, int h, int w_, int c, int cpg);

@@ -221,6 +221,14 @@ def test_grouped_conv3x3(pkg, c, cpg, hw, dtype):
     assert rel_l2(host(pkg, y), yr) < tol
     assert rel_l2(xd.grad.cpu(), xr.grad) < tol
     assert rel_l2(wd.grad.cpu(), wr.grad) < tol
+    # BatchNorm partial sums from the kernel's epilogue (bf16, 4 channels per group), same output bit for bit
+    y2, stats = pkg.ops.gconv3x3(pkg.ops.as_activation(xd.detach(), dtype), wd.detach(), want_stats=True)
+    assert torch.equal(y2, y.detach())
+    assert (stats is not None) == (dtype == torch.bfloat16 and cpg == 4 and (c // 4 >= 64 or 64 % (c // 4) == 0))
+    if stats is not None:
+        st, yf = stats.sum(0).cpu(), yr.detach().double()
+        assert rel_l2(st[:, 0], yf.sum((0, 2, 3))) < 5e-3 + tol
+        assert rel_l2(st[:, 1], (yf * yf).sum((0, 2, 3))) < 5e-3 + tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -62,6 +62,8 @@ SIGNATURES = {
     "ur_colsum": (_i, [_vp, _i, _ll, _i, _i, _vp, _vp, _sz, _vp]),
     "ur_gconv3x3_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_gconv3x3_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ur_gconv3x3_stats_rows": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ur_gconv3x3_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_gconv3x3_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "ur_gconv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_bn_stats_rows": (_sz, [_ll, _i]),

@@ -147,10 +147,12 @@ __global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__
 // tap's 4x4 weight block (bf16, 18 registers for all 9 taps).  Every lane walks down a column strip of RS
 // rows with a 3x3 register window: 3 loads per output instead of 9.
 //   grid.x = image * row strips * column strips, grid.y = quad blocks of QB = min(Q, 64) quads
-template <bool DGRAD>
+// STATS: also emit per-channel partial sums (sum, sum of squares of the fp32 results) for a following BatchNorm, one
+// row per blockIdx.x: stats[gridDim.x][C][2].
+template <bool DGRAD, bool STATS>
 __global__ __launch_bounds__(NT) void gconv3x3_mfma_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                            bf16_t* __restrict__ out, int H, int W, int C, int QB, int RS,
-                                                           int xstrips, int ystrips) {
+                                                           int xstrips, int ystrips, float* __restrict__ stats) {
     const int lane4 = threadIdx.x & 3;
     const int gb = threadIdx.x >> 2;                         // 0..63: block index within the workgroup
     const int q = blockIdx.y * QB + gb % QB;
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(NT) void gconv3x3_mfma_kernel(const bf16_t* __restr
         row[2] = (yok && xr) ? *reinterpret_cast<const s16x4_t*>(p + C) : zero;
     };
     s16x4_t win[3][3];
+    float st[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     load_row(y0 - 1, win[0]);
     load_row(y0, win[1]);
     for (int y = y0; y < y1; ++y) {
@@ -198,8 +201,31 @@ __global__ __launch_bounds__(NT) void gconv3x3_mfma_kernel(const bf16_t* __restr
             for (int kx = 0; kx < 3; ++kx)
                 acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wt[ky * 3 + kx], DGRAD ? win[2 - ky][2 - kx] : win[ky][kx], acc, 0, 0, 0);
         if (xin) ur_store4(out + (((size_t)n * H + y) * W + x) * C + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        if constexpr (STATS) {
+            if (xin) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { st[k] += acc[k]; st[4 + k] += acc[k] * acc[k]; }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { win[0][k] = win[1][k]; win[1][k] = win[2][k]; }
+    }
+    if constexpr (STATS) {
+        // thread t = ((pixel group * QB + local quad) << 2) + pixel lane; fixed summation order over the 4 * PG threads
+        // that hold the same quad
+        __shared__ float red[NT][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = st[k];
+        __syncthreads();
+        for (int o = threadIdx.x; o < QB * 8; o += NT) {
+            const int ql = o >> 3, k = o & 7;
+            float t = 0.f;
+            for (int g = 0; g < PG; ++g)
+#pragma unroll
+                for (int l = 0; l < 4; ++l) t += red[((g * QB + ql) << 2) + l][k];
+            const int ch = (blockIdx.y * QB + ql) * 4 + (k & 3);
+            stats[((size_t)blockIdx.x * C + ch) * 2 + (k >> 2)] = t;
+        }
     }
 }
 
@@ -209,17 +235,34 @@ static bool mfma_gconv_ok(int c, int cpg) {
     return cpg == 4 && (Q >= 64 ? Q % 64 == 0 : 64 % Q == 0);
 }
 
+struct GconvPlan { int Q, QB, xstrips, ystrips, RS; };
+GconvPlan gconv_mfma_plan(int n, int h, int w_, int c) {
+    GconvPlan p;
+    p.Q = c / 4;
+    p.QB = p.Q < 64 ? p.Q : 64;
+    const int PG = 64 / p.QB;
+    p.xstrips = ur_cdiv(w_, 4 * PG);
+    p.RS = 32;
+    while (p.RS > 4 && (long long)n * ur_cdiv(h, p.RS) * p.xstrips * (p.Q / p.QB) < 2048) p.RS >>= 1;
+    p.ystrips = ur_cdiv(h, p.RS);
+    return p;
+}
+
 template <bool DGRAD>
-void launch_gconv_mfma(const bf16_t* in, const float* w, bf16_t* out, int n, int h, int w_, int c, hipStream_t st) {
-    const int Q = c / 4;
-    const int QB = Q < 64 ? Q : 64;
-    const int PG = 64 / QB;
-    const int xstrips = ur_cdiv(w_, 4 * PG);
-    int RS = 32;
-    while (RS > 4 && (long long)n * ur_cdiv(h, RS) * xstrips * (Q / QB) < 2048) RS >>= 1;
-    const int ystrips = ur_cdiv(h, RS);
-    hipLaunchKernelGGL((gconv3x3_mfma_kernel<DGRAD>), dim3((unsigned)(n * ystrips * xstrips), Q / QB), dim3(NT), 0, st, in, w, out,
-                       h, w_, c, QB, RS, xstrips, ystrips);
+void launch_gconv_mfma(const bf16_t* in, const float* w, bf16_t* out, int n, int h, int w_, int c, hipStream_t st,
+                       float* stats = nullptr) {
+    const GconvPlan p = gconv_mfma_plan(n, h, w_, c);
+    const dim3 grid((unsigned)(n * p.ystrips * p.xstrips), p.Q / p.QB);
+    if (stats)
+        hipLaunchKernelGGL((gconv3x3_mfma_kernel<DGRAD, true>), grid, dim3(NT), 0, st, in, w, out, h, w_, c, p.QB, p.RS, p.xstrips,
+                           p.ystrips, stats);
+    else
+        hipLaunchKernelGGL((gconv3x3_mfma_kernel<DGRAD, false>), grid, dim3(NT), 0, st, in, w, out, h, w_, c, p.QB, p.RS, p.xstrips,
+                           p.ystrips, stats);
+}
+
+bool gconv_mfma_used(int dtype, int n, int h, int w_, int c, int cpg) {
+    return dtype == UR_BF16 && mfma_gconv_ok(c, cpg) && (long long)n * ur_cdiv(h, 4) * ur_cdiv(w_, 4) < (1LL << 31);
 }
 
 template <typename T, bool DGRAD>
@@ -227,7 +270,7 @@ void launch_gconv(const T* in, const float* w, T* out, int n, int h, int w_, int
     const int Q = c / 4;
     const long long P = (long long)n * h * w_;
     if constexpr (ElemTraits<T>::dtype == UR_BF16) {
-        if (mfma_gconv_ok(c, cpg) && (long long)n * ur_cdiv(h, 4) * ur_cdiv(w_, 4) < (1LL << 31)) {
+        if (gconv_mfma_used(UR_BF16, n, h, w_, c, cpg)) {
             launch_gconv_mfma<DGRAD>(in, w, out, n, h, w_, c, st);
             return;
         }
@@ -377,6 +420,21 @@ int ur_gconv3x3_fwd(const void* x, const float* w, void* y, int dtype, int n, in
     if (int e = check_args(x, w, y, dtype, n, h, w_, c, cpg)) return e;
     UR_DISPATCH_DTYPE(dtype, (launch_gconv<T, false>((const T*)x, w, (T*)y, n, h, w_, c, cpg, (hipStream_t)s)));
     return ur_check_launch("gconv3x3_fwd");
+}
+
+int ur_gconv3x3_stats_rows(int dtype, int n, int h, int w_, int c, int cpg) {
+    if (n <= 0 || h <= 0 || w_ <= 0 || c <= 0 || !gconv_mfma_used(dtype, n, h, w_, c, cpg)) return 0;
+    const GconvPlan p = gconv_mfma_plan(n, h, w_, c);
+    return n * p.ystrips * p.xstrips;
+}
+
+int ur_gconv3x3_fwd_stats(const void* x, const float* w, void* y, float* stats, int dtype, int n, int h, int w_, int c, int cpg,
+                          ur_stream_t s) {
+    if (int e = check_args(x, w, y, dtype, n, h, w_, c, cpg)) return e;
+    UR_REQUIRE(stats && gconv_mfma_used(dtype, n, h, w_, c, cpg),
+               "gconv3x3_fwd_stats: statistics come from the bf16 4-channels-per-group kernel only (ur_gconv3x3_stats_rows == 0 otherwise)");
+    launch_gconv_mfma<false>((const bf16_t*)x, w, (bf16_t*)y, n, h, w_, c, (hipStream_t)s, stats);
+    return ur_check_launch("gconv3x3_fwd_stats");
 }
 
 int ur_gconv3x3_dgrad(const void* dy, const float* w, void* dx, int dtype, int n, int h, int w_, int c, int cpg, ur_stream_t s) {

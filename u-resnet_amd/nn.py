@@ -66,6 +66,8 @@ class Conv2d(tnn.Conv2d):
         if self.groups != 1:
             if want_alias:
                 raise NotImplementedError("grouped Conv2d has no input alias")
+            if want_stats:
+                return ops.gconv3x3(x, self.weight, True)
             return ops.gconv3x3(x, self.weight), None
         return ops.conv2d(x, self.weight, self.bias, self._packs, self._s, self._p, want_stats, out, want_alias)
 

@@ -632,7 +632,7 @@ class _GConv3x3(Function):
     """Grouped 3x3, stride 1, pad 1, with 1 or 4 channels per group."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats):
         _require_gpu(x)
         c, cpg, kh, kw = weight.shape
         n, cx, h, w = x.shape
@@ -640,12 +640,23 @@ class _GConv3x3(Function):
             raise RuntimeError("grouped conv: only 3x3 with 1 or 4 channels per group is implemented "
                                "(weight %s, input %s)" % (tuple(weight.shape), tuple(x.shape)))
         y = torch.empty_like(x, memory_format=CL)
-        call("ur_gconv3x3_fwd", x.data_ptr(), weight.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, cpg, _stream())
+        rows = query("ur_gconv3x3_stats_rows", _dt(x), n, h, w, c, cpg) if want_stats else 0
+        stats = None
+        if rows:          # BatchNorm partial sums from the kernel's epilogue instead of a separate pass over y
+            stats = torch.empty((rows, c, 2), dtype=torch.float32, device=x.device)
+            call("ur_gconv3x3_fwd_stats", x.data_ptr(), weight.data_ptr(), y.data_ptr(), stats.data_ptr(), _dt(x), n, h, w, c,
+                 cpg, _stream())
+            ctx.mark_non_differentiable(stats)
+        else:
+            call("ur_gconv3x3_fwd", x.data_ptr(), weight.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, cpg, _stream())
         ctx.save_for_backward(x, weight)
-        return y
+        ctx.set_materialize_grads(False)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
+        if dy is None:
+            return None, None, None
         x, weight = ctx.saved_tensors
         c, cpg = weight.shape[0], weight.shape[1]
         n, _, h, w = x.shape
@@ -660,11 +671,13 @@ class _GConv3x3(Function):
             ws = _workspace(query("ur_gconv3x3_wgrad_workspace", n, h, w, c, cpg), x.device)
             call("ur_gconv3x3_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), _dt(x),
                  n, h, w, c, cpg, _stream())
-        return dx, dw
+        return dx, dw, None
 
 
-def gconv3x3(x, weight):
-    return _GConv3x3.apply(x, weight)
+def gconv3x3(x, weight, want_stats=False):
+    """y, or (y, stats or None) with want_stats: per-channel partial sums for a following training-mode BatchNorm."""
+    y, stats = _GConv3x3.apply(x, weight, want_stats)
+    return (y, stats) if want_stats else y
 
 
 # ------------------------------------------------------------------------------ batch norm (+act, +residual)
