@@ -2,7 +2,12 @@
 """Headline benchmark: U-ResNet Cityscapes-shaped 512x1024 bf16 training, images/sec.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 runs one process per GPU.  Either an outer launcher provides the ranks
+(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...: WORLD_SIZE is set), or this
+script starts them itself: with --gpus N > 1 and no WORLD_SIZE in the environment the parent process spawns
+`python -m torch.distributed.run` with N ranks BEFORE importing torch or touching a GPU, relays rank 0's
+JSON line and exits with the launcher's return code.
 
 One step = one pass of the hot path over one synthetic batch: NCHW fp32 images already resident in
 HBM -> UResNetNewEUCB(19, 3, 64) forward -> CE(ignore 255) -> backward -> [gradient all-reduce] ->
@@ -41,7 +46,102 @@ def parse():
                          "the default brackets only the dominant kernel's launches")
     ap.add_argument("--per-shape", action="store_true", help="print per-(kernel, shape) conv timings to stderr")
     ap.add_argument("--per-shape-top", type=int, default=40)
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="launch-path rehearsal without a GPU: the ranks rendezvous over gloo and push a small stand-in "
+                         "torch.nn network through ddp.DataParallel; exercises spawning, bucketed all-reduce, the "
+                         "max-over-ranks clock and the JSON line.  Not a measurement (the line says so)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """--gpus N > 1 without an outer launcher: start N ranks as children of this process, which has not imported torch
+    and never touches a GPU (a process that has initialised the GPU must not be replaced or forked into ranks)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4" if args.rehearse_cpu else "16")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def rehearse_cpu(args):
+    """Stand-in workload for --rehearse-cpu: same launch, sharding, DataParallel buckets, global valid-pixel count,
+    fences and JSON line as the real run, on a two-layer torch.nn network over gloo."""
+    import torch
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    import uresnet_amd
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    torch.manual_seed(rank)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 19, 1))
+    ddp = uresnet_amd.ddp.DataParallel(net, bucket_mb=0.0005) if world > 1 else None
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    B = 2
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(B, 3, 16, 32, generator=g)
+    y = torch.randint(0, 19, (B, 16, 32), generator=g)
+    y[torch.rand(y.shape, generator=g) < 0.1] = 255
+
+    def step():
+        out = net(x)
+        nll = F.cross_entropy(out, y, ignore_index=255, reduction="sum")
+        valid = (y != 255).sum().float()
+        count = valid.reshape(1)
+        if ddp is not None:
+            count = ddp.count_hook(torch.stack([nll.detach(), valid, nll.detach() / valid]))
+        loss = nll / count[0]
+        opt.zero_grad()
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss.detach()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    w0 = torch.cat([p.detach().flatten() for p in net.parameters()])
+    spread = torch.zeros(1)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lo, hi = w0.clone(), w0.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = (hi - lo).abs().max().reshape(1)
+    if rank == 0:
+        print(json.dumps({"metric": "launch-path rehearsal on CPU over gloo (NOT a measurement)", "rehearsal": True,
+                          "value": round(world * B * args.steps / float(t.item()), 3), "unit": "images/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "stand-in two-layer network 3x16x32, gloo", "per_gpu_batch": B,
+                                     "global_batch": B * world, "parallelism": "dp%d" % world,
+                                     "final_loss": round(float(loss), 5),
+                                     "max_weight_spread_across_ranks": float(spread.item())},
+                          "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def pmc_traffic(kernel):
@@ -81,6 +181,10 @@ def cpu_baseline(height, width):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
     import torch
     import torch.distributed as dist
     import uresnet_amd
@@ -91,8 +195,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
