@@ -294,6 +294,13 @@ int ur_seg_metrics_accumulate(const unsigned long long* cm, int classes, const f
 int ur_adam_multi(const void* const* ptrs, const long long* sizes, int ntensors, long long max_size, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                   ur_stream_t s);
+/* Adam with device-resident step counts (same update as ur_adam_multi; replaces the `step` bookkeeping of
+ * torch.optim.Adam, which train_UResNetAblitionStudy.py:122 advances once per optimizer.step()).  ptrs holds
+ * ntensors*5 pointers: (param, grad, exp_avg, exp_avg_sq, int32 step counter).  The call first adds 1 to every
+ * counter, then updates each tensor with the bias corrections of ITS counter.  No argument changes from step to
+ * step, so the launch pair can be captured in a HIP graph and replayed. */
+int ur_adam_multi_dev(const void* const* ptrs, const long long* sizes, int ntensors, long long max_size, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, ur_stream_t s);
 int ur_sgd_multi(const void* const* ptrs, const long long* sizes, int ntensors, long long max_size, float lr,
                  float weight_decay, float grad_scale, ur_stream_t s);
 

@@ -139,7 +139,7 @@ def test_checkpoint_and_optimizer_state_interchange(tmp_path, oracle):
         assert torch.equal(a, b), k
     for p, rp in zip(m.parameters(), ref.parameters()):
         st, rst = opt.state[p], ropt.state[rp]
-        assert st['step'] == 2 and isinstance(st['step'], int)
+        assert int(st['step']) == 2 and st['step'].dtype == torch.int32 and st['step'].device == p.device   # counter beside the parameter
         assert torch.equal(st['exp_avg'], rst['exp_avg']) and torch.equal(st['exp_avg_sq'], rst['exp_avg_sq'])
     # and back: our file into the reference-shaped model and torch's optimiser
     path2 = str(tmp_path / "ours.pth")

@@ -569,12 +569,102 @@ def test_graphed_sgd_step_replays_the_eager_step_bit_exactly(pkg):
     assert got == want
     for (k, a), b in zip(m.state_dict().items(), ref_m.state_dict().values()):
         assert torch.equal(a, b), k
-    with pytest.raises(NotImplementedError):
-        m2 = M.UResNet4_No_SU(10, 3, scale=3).set_compute_dtype(torch.bfloat16).to(DEV).train()
-        train.GraphedStep(train.cls_train_step, m2, train.Adam(m2.parameters(), lr=1e-4), xs[0], ys[0], warmup=1)
+    # An eager evaluation pass between replays must see the weights the replays wrote: the packed weight images that
+    # eager forwards cache are keyed on a counter the replay has to advance.
+    def eval_logits(model):
+        model.eval()
+        with torch.no_grad():
+            out = model(xs[0]).float().clone()
+        model.train()
+        return out
+
+    for rnd in range(2):
+        assert torch.equal(eval_logits(m), eval_logits(ref_m)), "evaluation after replay round %d" % rnd
+        for x, y in zip(xs[:2], ys[:2]):
+            a = step(x, y)[0].item()
+            b = train.cls_train_step(ref_m, ref_opt, x, y)[0].item()
+            assert a == b
+    assert torch.equal(eval_logits(m), eval_logits(ref_m))
+
+
+def test_graphed_adam_step_replays_the_eager_step_bit_exactly(pkg):
+    """The segmentation training step with Adam (train_UResNetAblitionStudy.py:115-122, :203) captured as a HIP graph:
+    the step counts live on the device, so replays apply the right bias corrections and match eager steps bit for bit;
+    the optimiser state written after replays carries the advanced counts."""
+    M, train = pkg.modules.U_ResNet, pkg.train
+
+    def build():
+        torch.manual_seed(0)
+        m = M.UResNetNewEUCB(19, 3, 8).set_compute_dtype(torch.bfloat16).to(DEV).train()
+        return m, train.Adam(m.parameters(), lr=1e-3)
+
+    g = torch.Generator().manual_seed(99)
+    xs = [torch.randn(2, 3, 32, 64, generator=g).to(DEV) for _ in range(4)]
+    ys = []
+    for _ in range(4):
+        y = torch.randint(0, 19, (2, 32, 64), generator=g)
+        y[torch.rand(y.shape, generator=g) < 0.1] = 255
+        ys.append(y.to(DEV))
+    m, opt = build()
+    step = train.GraphedStep(train.seg_train_step, m, opt, xs[0], ys[0], warmup=2)
+    ref_m, ref_opt = build()
+    for _ in range(step.warmup_steps):
+        train.seg_train_step(ref_m, ref_opt, xs[0], ys[0])
+    got = [step(x, y)[0].item() for x, y in zip(xs, ys)]
+    want = [train.seg_train_step(ref_m, ref_opt, x, y)[0].item() for x, y in zip(xs, ys)]
+    assert got == want
+    for (k, a), b in zip(m.state_dict().items(), ref_m.state_dict().values()):
+        assert torch.equal(a, b), k
+    sd, rsd = opt.state_dict(), ref_opt.state_dict()
+    steps = {float(v['step']) for v in sd['state'].values()}
+    assert steps == {float(step.warmup_steps + 4)} == {float(v['step']) for v in rsd['state'].values()}
+    for k in sd['state']:
+        assert torch.equal(sd['state'][k]['exp_avg'], rsd['state'][k]['exp_avg'])
+
+
+def test_adam_keeps_a_step_count_per_parameter(pkg):
+    """A parameter that first receives a gradient later starts its own bias correction then (torch.optim.Adam keeps
+    `step` per parameter)."""
+    train = pkg.train
+    torch.manual_seed(5)
+    a0, b0 = torch.randn(300, device=DEV), torch.randn(70, device=DEV)
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    ra, rb = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    opt, ropt = train.Adam([a, b], lr=1e-2), torch.optim.Adam([ra, rb], lr=1e-2)
+    for it in range(4):
+        ga, gb = torch.randn(300, device=DEV), torch.randn(70, device=DEV)
+        a.grad, ra.grad = ga.clone(), ga.clone()
+        if it >= 2:                                   # b joins two steps later
+            b.grad, rb.grad = gb.clone(), gb.clone()
+        opt.step()
+        ropt.step()
+    assert rel_l2(a.detach().cpu(), ra.detach().cpu()) < 2e-6
+    assert rel_l2(b.detach().cpu(), rb.detach().cpu()) < 2e-6
+    sd = opt.state_dict()['state']
+    assert float(sd[0]['step']) == 4.0 and float(sd[1]['step']) == 2.0
 
 
 # ----------------------------------------------------------------------------- fused concatenation paths
+def test_conv3x3_into_channel_window(pkg):
+    """ops.conv2d(out=window) for a bias-free 3x3 s1 p1 layer (the tile kernel): the result lands in the window with the
+    wider tensor's pixel pitch -- written by the kernel itself when pitch and address are 16-byte friendly, through a
+    pitched copy otherwise -- and the neighbouring channels stay untouched."""
+    ops = pkg.ops
+    torch.manual_seed(11)
+    n, cin, cout, h, w = 2, 32, 32, 12, 40
+    x = ops.as_activation(torch.randn(n, cin, h, w, device=DEV), torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, device=DEV) * 0.05
+    dense, _ = ops.conv2d(x, wt, None, ops.PackedWeights(), 1, 1)
+    for extra, c0 in ((16, 0), (16, 16), (20, 0), (12, 12)):        # pitches 48 (direct), 52 / 44 (copy), offset windows
+        buf = ops.empty_nhwc(n, cout + extra, h, w, torch.bfloat16, DEV).fill_(3.0)
+        win = ops.alias_window(buf, c0, cout)
+        got, _ = ops.conv2d(x, wt, None, ops.PackedWeights(), 1, 1, out=win)
+        assert got.data_ptr() == win.data_ptr()
+        assert torch.equal(buf[:, c0:c0 + cout], dense), (extra, c0)
+        rest = torch.cat([buf[:, :c0], buf[:, c0 + cout:]], 1)
+        assert bool((rest == 3.0).all()), (extra, c0)
+
+
 def test_channel_window_ops_are_bit_exact(pkg):
     """BatchNorm+ReLU into a channel window, max-pool from a window, ConvTranspose into a window == the dense ops."""
     ops = pkg.ops

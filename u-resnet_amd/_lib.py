@@ -101,6 +101,7 @@ SIGNATURES = {
     "ur_confusion_matrix": (_i, [_vp, _i, _vp, _ll, _i, _i, _ll, _vp, _vp]),
     "ur_seg_metrics_accumulate": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ur_adam_multi": (_i, [_vp, _vp, _i, _ll, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "ur_adam_multi_dev": (_i, [_vp, _vp, _i, _ll, _f, _f, _f, _f, _f, _f, _vp]),
     "ur_sgd_multi": (_i, [_vp, _vp, _i, _ll, _f, _f, _f, _vp]),
 }
 

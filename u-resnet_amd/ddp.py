@@ -40,24 +40,50 @@ class DataParallel:
     usage per step:
         out = ddp.module(x); loss = compute_loss(out, y, ddp.count_hook)
         optimizer.zero_grad(); loss.backward(); ddp.finish(); optimizer.step()
+
+    Buckets start in reverse registration order (head first, stem last).  The first step records the order in which
+    gradients really arrive -- the two branches of a U-ResNet interleave in backward, which registration order does
+    not show -- and the buckets are rebuilt once in that order, so that each one completes, and its all-reduce
+    starts, as early as the backward pass allows.
+
+    The backward-weight kernels write straight into their bucket slice (ops.grad_buffer asks `p._ur_grad_slot`), so
+    the large gradients are never copied into the bucket; gradients that arrive as separate tensors (biases,
+    BatchNorm parameters, padded layers) are copied by the hook.
+
+    Every rank must produce gradients for the same set of parameters (true for a replicated model with static
+    control flow): buckets in which no parameter received a gradient are skipped, and a rank that skipped a bucket
+    another rank reduces would leave the collective sequences out of step.  The first step checks this across ranks
+    and raises instead of deadlocking later.
     """
 
-    def __init__(self, module, process_group=None, bucket_mb=32.0, average=False, broadcast=True):
+    def __init__(self, module, process_group=None, bucket_mb=32.0, average=False, broadcast=True, reorder=True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (launch one process per GPU)")
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.average = average                  # True: mean of per-rank gradients; False: sum
+        self.bucket_mb = bucket_mb
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast:
-            for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, src=0, group=process_group)
-        # Buckets follow REVERSE registration order, which is close to the order backward
-        # produces gradients in (head first, stem last); readiness is tracked per parameter.
-        cap = int(bucket_mb * (1 << 20) / 4)
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t, src=0, group=process_group)
+            from . import ops
+            ops.bump_weights_epoch()            # packed weight images made before the broadcast are stale now
+        self._where = {}
+        self._build(list(reversed(params)))
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+        self._armed = True
+        self._arrival = [] if reorder else None  # parameters in the order their gradients arrived (first step only)
+        self._checked = False
+        self.bucket_order_source = "reverse registration"
+
+    def _build(self, ordered):
+        cap = int(self.bucket_mb * (1 << 20) / 4)
         self.buckets, cur, size = [], [], 0
-        for p in reversed(params):
+        for p in ordered:
             if cur and (size + p.numel() > cap or cur[0].device != p.device):
                 self.buckets.append(_Bucket(cur, cur[0].device))
                 cur, size = [], 0
@@ -65,12 +91,11 @@ class DataParallel:
             size += p.numel()
         if cur:
             self.buckets.append(_Bucket(cur, cur[0].device))
-        self._where = {}
+        self._where.clear()
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
-                p.register_post_accumulate_grad_hook(self._on_grad)
-        self._armed = True
+                p._ur_grad_slot = (lambda b=b, i=i: b.view(i))
 
     # -- loss normalisation over the global batch ------------------------------------------
     def count_hook(self, out3):
@@ -87,14 +112,29 @@ class DataParallel:
         if not self._armed:
             return
         b, i = self._where[p]
-        b.view(i).copy_(p.grad)
+        if self._arrival is not None:
+            self._arrival.append(p)
+        slot = b.view(i)
+        if p.grad.data_ptr() != slot.data_ptr():     # not written in place by the backward kernel
+            slot.copy_(p.grad)
         b.had_grad[i] = True
         b.pending -= 1
-        if b.pending == 0:
+        if b.pending == 0 and self._checked:         # the first step launches from finish(), after the consistency check
             self._launch(b)
+
+    def _check_same_gradient_sets(self):
+        flags = torch.tensor([float(h) for b in self.buckets for h in b.had_grad], device=self.buckets[0].flat.device)
+        lo, hi = flags.clone(), flags.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("DataParallel: ranks produced gradients for different sets of parameters")
 
     def finish(self):
         """Wait for every bucket; parameters then read their reduced gradient straight from the bucket."""
+        if not self._checked:
+            self._check_same_gradient_sets()
+            self._checked = True
         for b in self.buckets:
             if b.work is None:                   # some parameters never produced a gradient
                 if not any(b.had_grad):
@@ -116,6 +156,24 @@ class DataParallel:
                     p.grad = b.view(i)
             self._armed = True
             self._reset(b)
+        if self._arrival is not None:
+            self._reorder()
+
+    def _reorder(self):
+        """Rebuild the buckets once, in the order the first backward pass delivered the gradients (parameters that got
+        none keep their place at the end).  The reduced gradients of this step stay where they are: p.grad keeps the old
+        bucket alive until the next zero_grad."""
+        seen, order = set(), []
+        for p in self._arrival:
+            if id(p) not in seen:
+                seen.add(id(p))
+                order.append(p)
+        rest = [p for b in self.buckets for p in b.params if id(p) not in seen]
+        self._arrival = None
+        current = [p for b in self.buckets for p in b.params]
+        if [id(p) for p in order + rest] != [id(p) for p in current]:
+            self._build(order + rest)
+            self.bucket_order_source = "gradient arrival order of the first step"
 
     @staticmethod
     def _reset(b):

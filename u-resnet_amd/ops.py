@@ -308,6 +308,20 @@ def _conv_flops(d, transposed=False):
     return 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
 
 
+def grad_buffer(param, shape=None):
+    """Tensor a backward-weight kernel writes the gradient of `param` into.  A data-parallel wrapper may register
+    `param._ur_grad_slot`, a callable returning a fresh view of the parameter's slice of a gradient bucket: the kernel
+    then fills the bucket directly and autograd adopts the view as `param.grad` without a copy.  Only when no gradient
+    is held yet (an accumulation `grad += dw` must not alias its own operand)."""
+    shape = tuple(param.shape) if shape is None else tuple(shape)
+    slot = getattr(param, "_ur_grad_slot", None)
+    if slot is not None and param.grad is None and shape == tuple(param.shape):
+        t = slot()
+        if t.dtype == param.dtype and t.device == param.device and t.is_contiguous() and tuple(t.shape) == shape:
+            return t
+    return torch.empty(shape, dtype=param.dtype, device=param.device)
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -357,13 +371,19 @@ class _Conv2d(Function):
         d = _desc(x.shape, cout, kh, kw, stride, pad, x.dtype)
         if d.oh <= 0 or d.ow <= 0:
             raise RuntimeError("conv2d: kernel %dx%d does not fit input %dx%d" % (kh, kw, d.h, d.w))
-        tile = bias is None and use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 0)
         win_ld = 0
         if out is not None:                          # (window,): a channel window of a wider tensor (alias_window)
             win_ld = _channel_pitch(out[0])
             if tuple(out[0].shape) != (d.n, cout, d.oh, d.ow) or out[0].dtype != x.dtype or not win_ld:
                 raise RuntimeError("conv2d: `out` must be a channel window with the output's shape and dtype")
-        y = out[0] if (win_ld and not tile) else empty_nhwc(d.n, cout, d.oh, d.ow, x.dtype, x.device)
+        tile = bias is None and use_tile_kernel and query("ur_conv3x3_tile_supported", C.byref(d), 0)
+        tile_direct = False                          # the tile kernel writes the window itself when pitch and address allow
+        if tile and win_ld and win_ld % 8 == 0 and out[0].data_ptr() % 16 == 0:
+            d.out_ld = win_ld
+            tile_direct = bool(query("ur_conv3x3_tile_supported", C.byref(d), 0))
+            if not tile_direct:
+                d.out_ld = cout
+        y = out[0] if (win_ld and (not tile or tile_direct)) else empty_nhwc(d.n, cout, d.oh, d.ow, x.dtype, x.device)
         stats = None
         if tile:
             wp = packs.get_tile(weight, d, False)
@@ -391,8 +411,9 @@ class _Conv2d(Function):
                     stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
                 with _Timed("igemm_fwd", _conv_flops(d), d):
                     call("ur_conv2d_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stats), C.byref(d), _stream())
-        if win_ld and tile:                          # the tile kernel writes dense tensors only
-            _copy_channels(y, 0, cout, out[0], 0)
+        if win_ld and tile and not tile_direct:      # dense result -> rows of the window, win_ld elements apart
+            call("ur_copy_channels", y.data_ptr(), cout, 0, d.oh, d.ow, out[0].data_ptr(), win_ld, 0, d.oh, d.ow, 0, 0,
+                 d.n, cout, _dt(y), _stream())
             y = out[0]
         ctx.save_for_backward(x, weight)          # x: as the kernel saw it (channel-padded on the generic path)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
@@ -459,7 +480,7 @@ class _Conv2d(Function):
                 dalias = _g(dalias)
                 call("ur_add_inplace", dx.data_ptr(), dalias.data_ptr(), _dt(dx), dx.numel(), _stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((d.cout, d.cin, d.kh, d.kw), dtype=weight.dtype, device=weight.device)
+            dw = grad_buffer(weight, (d.cout, d.cin, d.kh, d.kw))
             if tile_w:
                 ws = _workspace(query("ur_wgrad3x3_tile_workspace", C.byref(d)), x.device)
                 with _Timed("tile_wgrad", _conv_flops(d), d):
@@ -554,7 +575,7 @@ class _ConvT2x2(Function):
             with _Timed("igemm_dgrad", _conv_flops(d, True), d):
                 call("ur_convT2x2_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
+            dw = grad_buffer(weight)
             ws = _workspace(query("ur_convT2x2_wgrad_workspace", C.byref(d)), x.device)
             with _Timed("wgrad", _conv_flops(d, True), d):
                 call("ur_convT2x2_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -609,7 +630,7 @@ class _ConvT2x2Cat(Function):
             with _Timed("igemm_dgrad", _conv_flops(d, True), d):
                 call("ur_convT2x2_dgrad", dy_ptr, wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
+            dw = grad_buffer(weight)
             ws = _workspace(query("ur_convT2x2_wgrad_workspace", C.byref(d)), x.device)
             with _Timed("wgrad", _conv_flops(d, True), d):
                 call("ur_convT2x2_wgrad", x.data_ptr(), dy_ptr, dw.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(d), _stream())

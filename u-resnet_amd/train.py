@@ -172,11 +172,30 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
 
 class Adam(_MultiTensorOptimizer):
     """torch.optim.Adam semantics (no amsgrad): exp_avg / exp_avg_sq state, bias correction, eps outside sqrt.
-    state_dict() / load_state_dict() use torch.optim.Adam's layout (`step` as a float32 scalar tensor), so optimiser
-    states move between the two in either direction; internally the step count is a Python int."""
+
+    Every parameter's step count lives in device memory (one int32 slot of a per-group pool; `state[p]['step']` is a
+    0-dim view of it) and is advanced by the kernel, so a step carries no host-side value: a captured HIP graph
+    replays it correctly, and parameters whose state began later are corrected with their own count, as
+    torch.optim.Adam does.  state_dict() / load_state_dict() use torch.optim.Adam's layout (`step` as a float32 CPU
+    scalar tensor), so optimiser states move between the two in either direction."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._step_pools = {}
+
+    def _step_slot(self, gi, p):
+        """0-dim int32 device view: the step counter of parameter p of group gi."""
+        group = self.param_groups[gi]
+        pool = self._step_pools.get(gi)
+        if pool is None or pool.numel() != len(group['params']) or pool.device != p.device:
+            if p.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("Adam: run at least one eager step before capturing")
+            pool = torch.zeros(len(group['params']), dtype=torch.int32, device=p.device)
+            self._step_pools[gi] = pool
+            self._pool_index = getattr(self, '_pool_index', {})
+            for i, q in enumerate(group['params']):
+                self._pool_index[q] = (gi, i)
+        return pool[self._pool_index[p][1]]
 
     def state_dict(self):
         sd = super().state_dict()
@@ -195,9 +214,14 @@ class Adam(_MultiTensorOptimizer):
         slim = {'state': state_dict['state'],
                 'param_groups': [{k: v for k, v in g.items() if k in keep} for g in state_dict['param_groups']]}
         super().load_state_dict(slim)
-        for st in self.state.values():
-            if 'step' in st and torch.is_tensor(st['step']):
-                st['step'] = int(round(float(st['step'])))
+        self._step_pools = {}
+        for gi, group in enumerate(self.param_groups):
+            for p in group['params']:
+                st = self.state.get(p)
+                if st and 'step' in st:
+                    count = int(round(float(st['step'])))
+                    st['step'] = self._step_slot(gi, p)
+                    st['step'].fill_(count)
         self._table_key = None
 
     @torch.no_grad()
@@ -211,20 +235,16 @@ class Adam(_MultiTensorOptimizer):
             for p in ps:
                 st = self.state[p]
                 if not st:
-                    st['step'] = 0
+                    st['step'] = self._step_slot(gi, p)
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
-                st['step'] += 1
-                rows.append((p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()))
+                rows.append((p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
+                             st['step'].data_ptr()))
                 sizes.append(p.numel())
-            step = self.state[ps[0]]['step']
-            if torch.cuda.is_current_stream_capturing():
-                raise NotImplementedError("Adam: the step count enters the kernel as a host scalar (bias correction); "
-                                          "a captured graph would replay a stale one.  Capture SGD steps, or run Adam eagerly")
             table, sz, mx = self._pointer_table(rows, sizes, ps[0].device)
             b1, b2 = group['betas']
-            _lib.call("ur_adam_multi", table.data_ptr(), sz.data_ptr(), len(ps), mx, group['lr'], b1, b2, group['eps'],
-                      group['weight_decay'], step, self.grad_scale, ops._stream())
+            _lib.call("ur_adam_multi_dev", table.data_ptr(), sz.data_ptr(), len(ps), mx, group['lr'], b1, b2, group['eps'],
+                      group['weight_decay'], self.grad_scale, ops._stream())
         ops.bump_weights_epoch()
         return loss
 
@@ -257,8 +277,9 @@ class GraphedStep:
     """One training step captured as a HIP graph and replayed: for small inputs the step is bound by the few hundred
     host-side launches, not by the GPU (CIFAR-shaped batch: 9 ms eager).  `step_fn(model, optimizer, *inputs)` is one of
     the *_train_step functions; inputs are copied into static buffers before each replay, the returned loss / outputs
-    are static tensors that the next replay overwrites.  Plain-SGD optimisers only (see Adam.step); shapes are fixed at
-    construction; BatchNorm running statistics and counters advance on the device as in eager mode."""
+    are static tensors that the next replay overwrites.  Works with this module's SGD and Adam (whose step counts live on
+    the device); shapes are fixed at construction; BatchNorm running statistics and counters advance on the device as in
+    eager mode."""
 
     def __init__(self, step_fn, model, optimizer, *example_inputs, warmup=3):
         import gc
@@ -281,6 +302,9 @@ class GraphedStep:
         for dst, src in zip(self._static, inputs):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replayed update rewrote the parameters through raw pointers: weight images cached by eager forwards
+        # (an evaluation pass between training epochs) are stale now, and nothing else tells the caches so
+        ops.bump_weights_epoch()
         return self._out
 
 
