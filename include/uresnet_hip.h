@@ -266,6 +266,16 @@ int ur_ce_fwd(const void* logits, int dtype, const int64_t* target, long long ro
 int ur_ce_bwd(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
               long long ignore_index, const float* lse, const float* count, const float* gout, void* dlogits,
               int dld, ur_stream_t s);
+/* ur_ce_fwd without a workspace argument and without any allocation.  No counterpart in the reference: it exists for
+ * callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  The per-workgroup partial sums live in a device array inside the library (8 KiB per GPU, held
+ * until the process ends; each GPU has its own copy, whose address is resolved on the first call made with that GPU
+ * current).  Same kernels, same results as ur_ce_fwd bit for bit.  rows > ur_ce_fwd_noalloc_max_rows() (2^24) is
+ * rejected with UR_ERR_INVALID.  All calls on one GPU share the array: calls that overlap on one GPU (different
+ * streams or threads) race; calls on one stream, or otherwise ordered, are safe and need no clearing in between. */
+long long ur_ce_fwd_noalloc_max_rows(void);
+int ur_ce_fwd_noalloc(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
+                      long long ignore_index, float* lse, float* out3, ur_stream_t s);
 /* BCEWithLogits, mean over all elements: out3 = {sum, count, mean} */
 int ur_bce_fwd(const void* logits, int dtype, const float* target, long long count, float* out3, void* workspace,
                size_t ws_bytes, ur_stream_t s);

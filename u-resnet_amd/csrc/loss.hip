@@ -5,6 +5,7 @@
 //   The backward kernel rebuilds softmax from the saved log-sum-exp and scales by the
 //   device-resident valid count, so no host synchronisation sits between forward and backward.
 #include "ur_common.h"
+#include <pthread.h>
 
 namespace {
 
@@ -265,6 +266,39 @@ __global__ __launch_bounds__(64) void seg_metrics_kernel(const unsigned long lon
 
 int loss_blocks(long long n) { return ur_grid_1d(n, NT, 1024); }
 
+// ---- ur_ce_fwd_noalloc: per-workgroup partial sums in a device array that belongs to the library -------------------
+// One (NLL sum, valid count) pair per workgroup of the largest grid loss_blocks() hands out: 8 KiB per GPU, held from the
+// moment the code object is loaded on that GPU until the process ends.  In host code `ce_scratch` is only a handle for
+// hipGetSymbolAddress: each GPU has its own copy at its own address, resolved once per device and kept in ce_scratch_dev.
+constexpr int CE_NOALLOC_MAX_BLOCKS = 1024;
+constexpr long long CE_NOALLOC_MAX_ROWS = 1LL << 24;       // 64 rows per thread of the largest grid
+constexpr int CE_MAX_DEVICES = 64;
+static __device__ __align__(256) float ce_scratch[CE_NOALLOC_MAX_BLOCKS * 2];
+float* ce_scratch_dev[CE_MAX_DEVICES];                      // device address of ce_scratch on GPU i (nullptr: not resolved yet)
+pthread_mutex_t ce_scratch_lock = PTHREAD_MUTEX_INITIALIZER;
+
+// Device address of the current GPU's ce_scratch, or nullptr with the error string set.
+float* ce_scratch_for_current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CE_MAX_DEVICES) {
+        ur_set_error("ce_fwd_noalloc: cannot identify the current device (%d)", dev);
+        return nullptr;
+    }
+    pthread_mutex_lock(&ce_scratch_lock);
+    float* p = ce_scratch_dev[dev];
+    if (!p) {
+        void* addr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&addr, HIP_SYMBOL(ce_scratch));
+        if (e != hipSuccess || !addr) {
+            ur_set_error("ce_fwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+        } else {
+            p = ce_scratch_dev[dev] = (float*)addr;
+        }
+    }
+    pthread_mutex_unlock(&ce_scratch_lock);
+    return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -289,6 +323,23 @@ int ur_ce_fwd(const void* logits, int dtype, const int64_t* target, long long ro
     if (int e = ur_check_launch("ce_fwd")) return e;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, partial, grid, out3, 0.0);
     return ur_check_launch("ce_finalize");
+}
+
+long long ur_ce_fwd_noalloc_max_rows(void) { return CE_NOALLOC_MAX_ROWS; }
+
+int ur_ce_fwd_noalloc(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
+                      long long ignore_index, float* lse, float* out3, ur_stream_t s) {
+    UR_REQUIRE(logits && target && lse && out3 && rows > 0 && classes > 0 && ld >= classes, "ce_fwd_noalloc: bad arguments");
+    UR_REQUIRE(rows <= CE_NOALLOC_MAX_ROWS, "ce_fwd_noalloc: %lld rows exceed the limit of %lld (use ur_ce_fwd with a workspace)",
+               rows, CE_NOALLOC_MAX_ROWS);
+    const int grid = loss_blocks(rows);
+    UR_REQUIRE(grid <= CE_NOALLOC_MAX_BLOCKS, "ce_fwd_noalloc: grid of %d workgroups exceeds the scratch array", grid);
+    float* partial = ce_scratch_for_current_device();
+    if (!partial) return UR_ERR_INVALID;
+    // every workgroup of the grid overwrites its own pair and the finalizer reads exactly `grid` pairs: whatever an
+    // earlier call left in the array is never read, so nothing needs clearing
+    return ur_ce_fwd(logits, dtype, target, rows, classes, ld, ignore_index, lse, out3, partial,
+                     (size_t)grid * 2 * sizeof(float), s);
 }
 
 int ur_ce_bwd(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
