@@ -8,6 +8,7 @@ fixtures are data only: tensors, scalars and sha256 digests.
 
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
     python tests/golden/make_golden.py temp       # only the scratch-variant models of Classification/modules/temp.py
+    python tests/golden/make_golden.py more       # only the remaining classification classes and the dataset statements
 """
 import hashlib
 import importlib.util
@@ -167,6 +168,54 @@ def metrics_case():
     print("wrote seg_metrics")
 
 
+def dataset_case():
+    """Label remap and the no-transform image conversion of CityscapesSemantic (DataInstance/Cityscapes.py:191-194,
+    220-223, 238, 242).  The dataset module needs PIL / albumentations at import time and files on disk, so exactly those
+    statements are compiled on their own from the file's syntax tree and run on synthetic label-id and image arrays."""
+    import ast
+    import types
+    path = os.path.join(REF, "Segmentation/Cityscapes/DataInstance/Cityscapes.py")
+    tree = ast.parse(open(path, encoding="utf-8").read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CityscapesSemantic"][0]
+    fns = {n.name: n for n in cls.body if isinstance(n, ast.FunctionDef)}
+
+    def stmts(fn, lo, hi):
+        out = []
+
+        def walk(body):
+            for n in body:
+                if isinstance(n, (ast.Assign, ast.For)) and lo <= n.lineno and n.end_lineno <= hi:
+                    out.append(n)
+                else:
+                    for field in ("body", "orelse"):
+                        walk(getattr(n, field, []) or [])
+        walk(fn.body)
+        return out
+
+    table = stmts(fns["__init__"], 191, 194)            # valid_classes, class_map, ignore_index
+    remap = stmts(fns["__getitem__"], 220, 223)         # mask = 255; mask[label == k] = class_map[k]; semantic_label = mask
+    plain = stmts(fns["__getitem__"], 238, 238) + stmts(fns["__getitem__"], 242, 242)    # /255.0 image, .long() label
+    assert len(table) == 3 and len(remap) == 3 and len(plain) == 2, (len(table), len(remap), len(plain))
+    self = types.SimpleNamespace()
+    exec(compile(ast.Module(body=table, type_ignores=[]), path, "exec"), {"self": self})
+    rng = np.random.RandomState(31)
+    ids = rng.randint(0, 34, size=(2, 24, 40)).astype(np.uint8)       # raw Cityscapes ids 0..33
+    ids[0, :2] = 255                                                  # and values outside the id range
+    ids[1, 5, :7] = 200
+    img = rng.randint(0, 256, size=(2, 24, 40, 3)).astype(np.uint8)
+    rec = {"ids": ids, "image": img, "valid_classes": np.array(self.valid_classes), "ignore_index": np.array(self.ignore_index)}
+    targets, images = [], []
+    for i in range(2):
+        ns = {"self": self, "np": np, "torch": torch, "semantic_label": ids[i], "image": img[i]}
+        exec(compile(ast.Module(body=remap + plain, type_ignores=[]), path, "exec"), ns)
+        targets.append(npy(ns["semantic_label"]))
+        images.append(npy(ns["image"]))
+    rec["target"] = np.stack(targets)          # int64, 19 classes + 255
+    rec["image_div255"] = np.stack(images)     # CHW float32
+    np.savez(os.path.join(OUT, "cityscapes_dataset.npz"), **rec)
+    print("wrote cityscapes_dataset", rec["target"].dtype, rec["image_div255"].shape)
+
+
 SELECTED = ("conv1.0.weight", "ResLayer2.0.shortcut.0.weight", "ResLayer4.1.left.3.weight", "Upsample.pwc.0.weight",
             "in_conv.0.weight", "down2.1.3.weight", "up1.up.weight", "up1.up.bias", "up4.conv.0.weight",
             "out_conv.0.weight", "out_conv.0.bias", "out_conv.2.weight", "out_conv.2.bias", "down4.1.1.weight")
@@ -257,6 +306,8 @@ def cls_model_case(name, build, nclass, shape, lr, steps=3):
 
 def main():
     torch.set_num_threads(8)
+    if "more" in sys.argv[1:]:
+        return main_more()
     if "temp" not in sys.argv[1:]:
         main_families()
     temp = load_ref("temp")
@@ -293,6 +344,41 @@ def main_families():
     seg_model_case("seg_noEUCB_c8", lambda: seg.UResNetNoEUCB(19, 3, 8), 19, (1, 3, 32, 48), steps=1)
     seg_model_case("ice_noresblock_c8", lambda: ice.UResNetNoResBlock(1, 3, 8), 1, (1, 3, 32, 32), steps=1)
     cls_model_case("cifar_uresnet4_nosu", lambda: cifar.UResNet4_No_SU(10, 3, scale=3), 10, (4, 3, 32, 32), 0.01)
+    main_more(cifar, mini)
+
+
+def broken_case(cifar):
+    """The three classes of U_ResNet_CIFAR.py that cannot run at 32x32 as committed (:296, :342, :389): parameter names,
+    seeded initialisation, and the exception the reference's forward raises."""
+    import contextlib
+    import io
+    rec = {}
+    for name, build in (("U_ResNet", lambda: cifar.U_ResNet()), ("S_ResNet", lambda: cifar.S_ResNet()),
+                        ("NlNet", lambda: cifar.NlNet(10, 3))):
+        torch.manual_seed(0)
+        m = build().train()
+        rec[name + "/keys"] = np.array(list(m.state_dict().keys()))
+        rec[name + "/w0_sha"] = np.array([sha(v) for v in m.state_dict().values()])
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):          # NlNet prints its shapes before failing
+                m(randn((4, 3, 32, 32), 1234))
+            raise SystemExit(name + " unexpectedly ran")
+        except RuntimeError as e:
+            rec[name + "/error"] = np.array(str(e).splitlines()[0])
+    np.savez(os.path.join(OUT, "cifar_broken_classes.npz"), **rec)
+    print("wrote cifar_broken_classes", {k: str(v) for k, v in rec.items() if k.endswith("/error")})
+
+
+def main_more(cifar=None, mini=None):
+    """The other classification classes that run as committed, and the dataset statements in front of the hot path."""
+    cifar = cifar or load_ref("cifar")
+    mini = mini or load_ref("mini")
+    cls_model_case("cifar_uresnet3_noeucb", lambda: cifar.UResNet3_No_EUCB(10, 3, scale=3), 10, (4, 3, 32, 32), 0.01)
+    cls_model_case("cifar_uresnet3_noublock", lambda: cifar.UResNet3_No_UBlock(10, 3, scale=3), 10, (4, 3, 32, 32), 0.01)
+    cls_model_case("cifar_eresnet", lambda: cifar.E_ResNet(), 10, (4, 3, 32, 32), 0.01)
+    cls_model_case("mini_uresnet", lambda: mini.U_ResNet(100, 3), 100, (2, 3, 224, 224), 0.1, steps=2)
+    dataset_case()
+    broken_case(cifar)
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 header declares, the ctypes table covers the header, and the model classes keep the
 reference's constructor signatures and state_dict layout.  No kernel is launched here."""
 import ctypes
+import hashlib
 import inspect
 import re
 
@@ -89,6 +90,23 @@ def test_temp_variant_state_dict_layout(name, cls):
     assert list(sd.keys()) == list(rec["keys"])
     sha = [hashlib.sha256(v.contiguous().numpy().tobytes()).hexdigest() for v in sd.values()]
     assert sha == list(rec["w0_sha"])
+
+
+def test_shape_broken_cifar_classes_keep_signature_and_parameters():
+    """U_ResNet / S_ResNet / NlNet of U_ResNet_CIFAR.py (:296, :342, :389) cannot run at 32x32 in the reference; the
+    constructors still exist with the reference's signature, state_dict keys and seeded initialisation."""
+    from uresnet_amd.modules import U_ResNet_CIFAR as Cc
+    rec = load_golden("cifar_broken_classes")
+    sig = lambda c: list(inspect.signature(c.__init__).parameters)[1:]
+    assert sig(Cc.U_ResNet) == sig(Cc.S_ResNet) == ["num_classes", "in_channels", "ResidulBlock"]
+    assert sig(Cc.NlNet) == ["num_classes", "in_channels", "ResidulBlock", "scale"]
+    for name, build in (("U_ResNet", lambda: Cc.U_ResNet()), ("S_ResNet", lambda: Cc.S_ResNet()),
+                        ("NlNet", lambda: Cc.NlNet(10, 3))):
+        torch.manual_seed(0)
+        sd = build().state_dict()
+        assert list(sd.keys()) == list(rec[name + "/keys"]), name
+        sha = [hashlib.sha256(v.contiguous().numpy().tobytes()).hexdigest() for v in sd.values()]
+        assert sha == list(rec[name + "/w0_sha"]), name
 
 
 def test_constructor_signatures_follow_the_reference():

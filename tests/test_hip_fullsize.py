@@ -150,3 +150,62 @@ def test_config5_ice_seg_inference_mask(pkg, oracle):
         assert rel_l2(host(pkg, out), ro) < tol
         got = host(pkg, mask.float()).bool()
         assert (got != want).float().mean().item() < flips       # only logits within round-off of 0 may flip
+
+
+def test_config4_full_resolution_1024x2048(pkg, oracle):
+    """Config 4: one 1024x2048 image through UResNetNewEUCB(19,3,64).  Forward logits and loss against the oracle (train
+    mode, batch statistics; fp32 2e-4, bf16 against the bf16-storage oracle), then properties that need no oracle: the
+    LDS-tiled and the generic kernels agree on a whole bf16 training step, running statistics follow the oracle's, two
+    Adam steps keep the loss finite and falling, and a row too long for the tile kernel's 24-bit offsets is refused by
+    its support query (the generic kernel takes such a layer)."""
+    import ctypes as C
+    from uresnet_amd import _lib
+    x, y = _seg_inputs(1024, 2048)
+    torch.manual_seed(0)
+    ref = oracle.UResNetNewEUCB(19, 3, 64).train()
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    with torch.no_grad():
+        ro = ref(x)
+        rl = oracle.compute_loss(ro, y)
+    stats_ref = {k: v.clone() for k, v in ref.state_dict().items() if "running" in k}
+    ref.load_state_dict(state0)
+    hb = oracle.emulate_bf16_storage(ref)
+    with torch.no_grad():
+        ro_b = ref(x)
+        rl_b = oracle.compute_loss(ro_b, y)
+    del ref, hb
+    xd, yd = x.to(DEV), y.to(DEV)
+    res = {}
+    for dtype, tile in ((torch.float32, True), (torch.bfloat16, True), (torch.bfloat16, False)):
+        pkg.ops.use_tile_kernel = tile
+        try:
+            m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 64).set_compute_dtype(dtype)
+            m.load_state_dict(state0)
+            m.to(DEV).train()
+            opt = pkg.train.Adam(m.parameters(), lr=1e-4)
+            loss, out = pkg.train.seg_train_step(m, opt, xd, yd)
+            assert out.shape == (1, 19, 1024, 2048)
+            logits = host(pkg, out)
+            if dtype == torch.float32:
+                assert rel_l2(logits, ro) < 2e-4
+                assert abs(loss.item() - rl.item()) < 1e-5 * abs(rl.item())
+                for k, v in stats_ref.items():
+                    assert rel_l2(m.state_dict()[k].cpu(), v) < 1e-4, k
+            else:
+                assert rel_l2(logits, ro_b) < 4e-2
+                assert abs(loss.item() - rl_b.item()) < 2e-3 * abs(rl_b.item())
+            loss2, _ = pkg.train.seg_train_step(m, opt, xd, yd)
+            assert torch.isfinite(loss2).item() and loss2.item() < loss.item()
+            res[(dtype, tile)] = (logits, loss.item(), loss2.item())
+            del m, opt, out
+        finally:
+            pkg.ops.use_tile_kernel = True
+    a, b = res[(torch.bfloat16, True)], res[(torch.bfloat16, False)]
+    assert rel_l2(a[0], b[0]) < 2e-2 and abs(a[1] - b[1]) < 2e-3 and abs(a[2] - b[2]) < 2e-2
+    # the tile kernels address a pixel row with 24-bit element offsets: w * pitch must stay below 2^24
+    d = _lib.ConvDesc()
+    d.dtype, d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout = _lib.UR_BF16, 1, 32, 2048, 64, 32, 2048, 64
+    d.kh = d.kw = 3; d.stride = d.pad = 1; d.in_ld = d.out_ld = 64
+    assert _lib.query("ur_conv3x3_tile_supported", C.byref(d), 0) == 1
+    d.in_ld = 8192                                   # a 64-channel window of an 8192-channel tensor: 2048 * 8192 = 2^24
+    assert _lib.query("ur_conv3x3_tile_supported", C.byref(d), 0) == 0

@@ -546,6 +546,90 @@ def test_temp_variant_fp32_matches_reference(pkg, name, cls):
     assert np.allclose(losses, rec["losses"], rtol=2e-3), (losses, rec["losses"])
 
 
+@pytest.mark.parametrize("name, mod, cls, args, kwargs, lr", [
+    ("cifar_uresnet3_noeucb", "U_ResNet_CIFAR", "UResNet3_No_EUCB", (10, 3), {"scale": 3}, 0.01),
+    ("cifar_uresnet3_noublock", "U_ResNet_CIFAR", "UResNet3_No_UBlock", (10, 3), {"scale": 3}, 0.01),
+    ("cifar_eresnet", "U_ResNet_CIFAR", "E_ResNet", (), {}, 0.01),
+    ("mini_uresnet", "U_ResNet_MiniImageNet", "U_ResNet", (100, 3), {}, 0.1)])
+def test_classification_variant_fp32_matches_reference(pkg, name, mod, cls, args, kwargs, lr):
+    """The remaining runnable classification classes (U_ResNet_CIFAR.py:252,437,487; U_ResNet_MiniImageNet.py:321)
+    against fixtures recorded from the reference files: logits 2e-4, gradient norms, SGD loss curve."""
+    rec = load_golden(name)
+    torch.manual_seed(0)
+    m = getattr(getattr(pkg.modules, mod), cls)(*args, **kwargs).set_compute_dtype(torch.float32)
+    assert list(m.state_dict().keys()) == list(rec["keys"])
+    m.to(DEV).train()
+    x, y = torch.from_numpy(rec["x"]).to(DEV), torch.from_numpy(rec["target"]).to(DEV)
+    opt = pkg.train.SGD(m.parameters(), lr=lr)
+    losses = []
+    for s in range(len(rec["losses"])):
+        loss, out = pkg.train.cls_train_step(m, opt, x, y)
+        losses.append(loss.item())
+        if s == 0:
+            assert rel_l2(out.float().cpu(), rec["logits"]) < 2e-4
+            assert [k for k, p in m.named_parameters() if p.grad is None] == list(rec["nograd_keys"])
+            floor = 1e-5 * float(rec["grad_norm"].max())
+            errs = [abs(p.grad.double().norm().item() - n) / n
+                    for (k, p), n in zip([(k, p) for k, p in m.named_parameters() if p.grad is not None], rec["grad_norm"])
+                    if n > floor]
+            assert np.median(errs) < 1e-4 and max(errs) < 3e-2, (np.median(errs), max(errs))
+    assert np.allclose(losses, rec["losses"], rtol=5e-3, atol=2e-4), (losses, rec["losses"])
+
+
+@pytest.mark.parametrize("act", ["relu", "relu6", "leakyrelu", "gelu", "hswish"])
+def test_act_layer_variants_match_torch(pkg, act):
+    """act_layer (S/C:17-34): every activation the factory hands out except prelu, forward and backward against the
+    torch.nn layer the reference would construct, fp32 1e-5 and bf16 1e-2 (inputs rounded to bf16 first); kinks at 0,
+    +-3 and 6 are hit exactly."""
+    ref_layer = {"relu": torch.nn.ReLU(), "relu6": torch.nn.ReLU6(), "leakyrelu": torch.nn.LeakyReLU(0.2),
+                 "gelu": torch.nn.GELU(), "hswish": torch.nn.Hardswish()}[act]
+    layer = pkg.modules._blocks.act_layer(act, inplace=True)
+    assert type(layer).__name__ == type(ref_layer).__name__
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 16, 9, 13, generator=g) * 4
+    x[0, 0, 0, :6] = torch.tensor([0.0, -0.0, 3.0, -3.0, 6.0, -6.0])
+    go = torch.randn(2, 16, 9, 13, generator=g)
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        xr = x.detach().to(dtype).float().clone().requires_grad_(True)
+        yr = ref_layer(xr)
+        yr.backward(go.to(dtype).float())
+        xd = pkg.ops.as_activation(x.to(DEV), dtype).detach().requires_grad_(True)
+        yd = layer(xd)
+        yd.backward(pkg.ops.as_activation(go.to(DEV), dtype))
+        assert rel_l2(host(pkg, yd), yr.detach()) < tol, (act, dtype)
+        assert rel_l2(host(pkg, xd.grad), xr.grad) < tol, (act, dtype)
+    with pytest.raises(NotImplementedError):
+        pkg.modules._blocks.act_layer("prelu")
+    with pytest.raises(NotImplementedError):
+        pkg.modules._blocks.act_layer("swish")
+
+
+def test_shape_broken_cifar_classes_raise_the_reference_error(pkg):
+    """U_ResNet / S_ResNet / NlNet (U_ResNet_CIFAR.py:296, 342, 389) at 4x3x32x32: the layers run on the GPU up to the
+    point where the reference fails, and the same RuntimeError text comes out (recorded from the reference)."""
+    rec = load_golden("cifar_broken_classes")
+    Cc = pkg.modules.U_ResNet_CIFAR
+    x = torch.randn(4, 3, 32, 32, device=DEV)
+    for name, build in (("U_ResNet", lambda: Cc.U_ResNet()), ("S_ResNet", lambda: Cc.S_ResNet()),
+                        ("NlNet", lambda: Cc.NlNet(10, 3))):
+        m = build().set_compute_dtype(torch.float32).to(DEV).train()
+        with pytest.raises(RuntimeError) as err:
+            m(x)
+        assert str(err.value) == str(rec[name + "/error"]), name
+    with pytest.raises(RuntimeError, match="Expected size 8 but got size 12"):      # UResNet4_No_SU at its default scale
+        Cc.UResNet4_No_SU(10, 3).set_compute_dtype(torch.float32).to(DEV).train()(x)
+
+
+def test_dataset_step_matches_reference_fixture(pkg):
+    """Label remap and /255 image conversion on the GPU against outputs of the reference's own statements
+    (Cityscapes.py:191-194, 220-223, 238, 242): bit-exact."""
+    rec = load_golden("cityscapes_dataset")
+    got_t = pkg.data.remap_labels(torch.from_numpy(rec["ids"]).to(DEV))
+    assert got_t.dtype == torch.int64 and np.array_equal(got_t.cpu().numpy(), rec["target"])
+    x = pkg.data.pack_images(torch.from_numpy(rec["image"]).to(DEV), torch.float32, mean=None, std=None)
+    assert np.array_equal(host(pkg, x).numpy(), rec["image_div255"])
+
+
 def test_graphed_sgd_step_replays_the_eager_step_bit_exactly(pkg):
     """A training step captured as a HIP graph (train.GraphedStep) and replayed on new batches gives the same losses
     as the eager step from the same state: same kernels, same order, nothing data-dependent on the host."""

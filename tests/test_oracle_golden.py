@@ -155,6 +155,51 @@ def test_cifar_model_matches_reference(oracle):
 TEMP_CASES = {"temp_nlnet": "TempNlNet", "temp_uresnet2": "TempUResNet2", "temp_eresnet": "TempE_ResNet",
               "temp_uresnet": "TempU_ResNet"}
 
+# the remaining classification classes that run as committed: golden -> (oracle class, ctor args, ctor kwargs, SGD lr)
+CLS_CASES = {"cifar_uresnet3_noeucb": ("UResNet3_No_EUCB", (10, 3), {"scale": 3}, 0.01),
+             "cifar_uresnet3_noublock": ("UResNet3_No_UBlock", (10, 3), {"scale": 3}, 0.01),
+             "cifar_eresnet": ("E_ResNet", (), {}, 0.01),
+             "mini_uresnet": ("MiniU_ResNet", (100, 3), {}, 0.1)}
+
+
+@pytest.mark.parametrize("name", sorted(CLS_CASES))
+def test_classification_variant_matches_reference(oracle, name):
+    """Classification/modules/U_ResNet_CIFAR.py:252,437,487 at 4x3x32x32 and U_ResNet_MiniImageNet.py:321 at 2x3x224x224
+    (fixtures made from the reference files): state_dict keys, seeded initialisation, logits, which parameters get no
+    gradient, gradient norms and the SGD loss curve."""
+    cls, args, kwargs, lr = CLS_CASES[name]
+    rec = load_golden(name)
+    torch.manual_seed(0)
+    m = getattr(oracle, cls)(*args, **kwargs)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(rec["keys"])
+    assert [_sha(v) for v in sd.values()] == list(rec["w0_sha"])
+    m.train()
+    x, y = torch.from_numpy(rec["x"]), torch.from_numpy(rec["target"])
+    opt = torch.optim.SGD(m.parameters(), lr=lr)
+    losses = []
+    for s in range(len(rec["losses"])):
+        loss, out = oracle.cls_train_step(m, opt, x, y)
+        losses.append(loss.item())
+        if s == 0:
+            assert rel_l2(out, rec["logits"]) < 1e-5
+            assert [k for k, p in m.named_parameters() if p.grad is None] == list(rec["nograd_keys"])
+            for (k, p), n in zip([(k, p) for k, p in m.named_parameters() if p.grad is not None], rec["grad_norm"]):
+                assert abs(p.grad.double().norm().item() - n) <= 1e-3 * n + 1e-6, k
+    assert np.allclose(losses, rec["losses"], rtol=1e-4)
+
+
+def test_dataset_statements_match_reference(oracle):
+    """Label remap (Cityscapes.py:191-194, 220-223, 242) and the no-transform image conversion (:238) against outputs of
+    those very statements of the reference file.  A.Normalize itself stays unpinned: albumentations is not installed."""
+    rec = load_golden("cityscapes_dataset")
+    assert tuple(rec["valid_classes"]) == tuple(oracle.CITYSCAPES_VALID_CLASSES) and int(rec["ignore_index"]) == 255
+    for i in range(rec["ids"].shape[0]):
+        t = oracle.cityscapes_remap(rec["ids"][i])
+        assert t.dtype == torch.int64 and np.array_equal(t.numpy(), rec["target"][i])
+        img = oracle.normalize_to_tensor(rec["image"][i], mean=None)
+        assert img.dtype == torch.float32 and np.array_equal(img.numpy(), rec["image_div255"][i])
+
 
 @pytest.mark.parametrize("name", sorted(TEMP_CASES))
 def test_temp_variant_matches_reference(oracle, name):

@@ -416,7 +416,8 @@ __device__ __forceinline__ float act_grad(float x, int act, float slope) {
         float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
         return cdf + x * pdf;
     }
-    case UR_ACT_HSWISH: return x < -3.f ? 0.f : (x <= 3.f ? (2.f * x + 3.f) * (1.f / 6.f) : 1.f);
+    // torch's hardswish_backward: the sloped piece is the open interval (-3, 3); at -3 the gradient is 0, at 3 it is 1
+    case UR_ACT_HSWISH: return x <= -3.f ? 0.f : (x < 3.f ? (2.f * x + 3.f) * (1.f / 6.f) : 1.f);
     }
     return 1.f;
 }

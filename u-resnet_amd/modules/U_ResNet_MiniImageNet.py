@@ -99,4 +99,4 @@ class U_ResNet(_Cls):
         x = ops.as_activation(x, self.compute_dtype)
         logits = self.U_Net(x)
         out = self.Upsample(self._res_forward(x))
-        return self._head(ops.cat_pad(out, logits), 7)
+        return self._head(ops.cat_channels(out, logits), 7)

@@ -85,7 +85,7 @@ class NlNet(_Temp):
         x = ops.as_activation(x, self.compute_dtype)
         logits = self.U_Net(x)
         out = self.Upsample(self._trunk(x))
-        return self._head(ops.cat_pad(out, logits), 9)      # AvgPool2d(kernel_size=9, stride=9), C/T:304,331
+        return self._head(ops.cat_channels(out, logits), 9)      # AvgPool2d(kernel_size=9, stride=9), C/T:304,331
 
 
 class UResNet2(NlNet):
@@ -111,7 +111,7 @@ class E_ResNet(_Temp):
     def forward(self, x):
         x = ops.as_activation(x, self.compute_dtype)
         logits = ops.avg_pool2d(self.U_Net(x), 2)
-        return self._head(ops.cat_pad(self._trunk(x), logits), 7)
+        return self._head(ops.cat_channels(self._trunk(x), logits), 7)
 
 
 class U_ResNet(_Temp):

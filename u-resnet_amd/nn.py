@@ -162,6 +162,9 @@ class Linear(tnn.Linear):
         if x.dim() != 2:
             raise NotImplementedError("Linear: 2-D input expected")
         b, f = x.shape
+        if f != self.in_features:                  # torch's addmm message (the reference's mis-sized heads raise it)
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)"
+                               % (b, f, self.in_features, self.out_features))
         x4 = x.contiguous().view(b, f, 1, 1)
         w4 = self.weight.view(self.out_features, self.in_features, 1, 1)
         y, _ = ops.conv2d(x4, w4, self.bias, self._packs, 1, 0, False)

@@ -951,6 +951,18 @@ def cat_pad(a, b):
     return _CatPad.apply(a, b)
 
 
+def cat_channels(a, b):
+    """torch.cat([a, b], dim=1) with torch's own size check and message (the classification heads of the reference
+    concatenate without padding: mismatched feature maps are an error there, not something to paper over)."""
+    if a.dim() != 4 or b.dim() != 4:
+        raise RuntimeError("cat_channels: 4-D tensors expected")
+    for dim in (0, 2, 3):
+        if a.shape[dim] != b.shape[dim]:
+            raise RuntimeError("Sizes of tensors must match except in dimension 1. Expected size %d but got size %d for "
+                               "tensor number 1 in the list." % (a.shape[dim], b.shape[dim]))
+    return _CatPad.apply(a, b)
+
+
 class _CatWindows(Function):
     """torch.cat([a, b], dim=1) where a and b already ARE the two channel windows of `buf` (their producers wrote
     them in place, see alias_window): nothing is copied in either direction, the gradients are channel windows of
