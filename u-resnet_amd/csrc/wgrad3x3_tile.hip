@@ -15,6 +15,8 @@
 #include "ur_common.h"
 #include "wgrad32_tile.h"
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -58,6 +60,14 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* base0, const unsigned char* base1, int imm) {
     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base0 + imm));
     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base1 + imm));
+    s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, both);
+}
+
+// the same with 32-bit LDS byte addresses (half the registers of generic pointers)
+__device__ __forceinline__ bf16x8_t tr_frag_u(unsigned a0, unsigned a1, int imm) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)(a0 + imm));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)(a1 + imm));
     s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, both);
 }
@@ -178,6 +188,220 @@ __global__ __launch_bounds__(NTHREADS, MINW) void wgrad3x3_tile_kernel(WgTilePar
         }
 }
 
+// ---- version 2: vertical strips with a rolling halo ---------------------------------------------------------------------
+// A workgroup walks a contiguous run of tiles DOWN a 32-pixel column strip (tile order: image, column strip, row).  The
+// x halo of a 2-row tile is 4 rows, two of which the previous tile of the strip already staged: the LDS halo is a ring of
+// 4 row slots (global row y lives in slot (y + 1) & 3 relative to the strip start), and a tile loads only its 2 new rows.
+// Against version 1 (every tile stages all 4 rows, consecutive tiles go to different workgroups) this halves the x bytes
+// fetched and staged; dy is read once either way.  M16 selects v_mfma_f32_16x16x32_bf16 (K = the 32 pixels of a tile row,
+// 16 x 16 output blocks) instead of 32x32x16: same cycles per FLOP, a different operand footprint.
+template <typename F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int HPITCH2 = 48;                                // halo row pitch (pixels): a multiple of 16 keeps every swizzle bit lane-constant
+
+// 128-byte pixel rows in four 32-byte (16-channel) slots, slot index XORed with pixel bits 1 and 3: the 8 pixels x 32 bytes
+// that one 32-lane group of a transposing read touches (pixels w..w+3 and w+8..w+11 of one row) land on 8 distinct
+// 32-byte bank groups for every w.
+__device__ __forceinline__ int swz16(int pix, int c) {
+    return pix * 128 + ((((c >> 4) ^ ((pix >> 1) & 1) ^ (((pix >> 3) & 1) << 1)) & 3) << 5) + (c & 15) * 2;
+}
+
+template <bool M16>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_strip_kernel(WgTileParams p) {
+    constexpr int TH = 2;
+    constexpr int HP = M16 ? HPITCH2 : HPITCH;
+    constexpr int DY_PIX = TH * TW, DY_BYTES = DY_PIX * 128, HALO_BYTES = 4 * HP * 128;
+    constexpr int DY_ITERS = DY_PIX * 8 / NTHREADS;                                  // 2
+    constexpr int ROW_PIECES = HALO_COLS * 8;                                        // 272 16-byte pieces per halo row
+    constexpr int HALO_ITERS = (4 * ROW_PIECES + NTHREADS - 1) / NTHREADS;           // 5 (all four rows), 3 cover two
+    constexpr int HALO_ITERS2 = (2 * ROW_PIECES + NTHREADS - 1) / NTHREADS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DY_BYTES + HALO_BYTES];
+    unsigned char* dyl = lds;
+    unsigned char* xl = lds + DY_BYTES;
+    auto sw = [](int pix, int c) { return M16 ? swz16(pix, c) : swz(pix, c); };
+
+    int pair, split;
+    wg_decode(p, pair, split);
+    const int cob = pair / p.ci_blocks, cib = pair - cob * p.ci_blocks;
+    const int co0 = cob * BO, ci0 = cib * BI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int piece_ch = (tid & 7) * 8;
+
+    // tiles [l0, l1) of the order (image, column strip, row); ty runs fastest
+    const int per = (p.tiles + p.nsplit - 1) / p.nsplit;
+    const int l0 = split * per, l1 = (l0 + per < p.tiles) ? l0 + per : p.tiles;
+
+    bf16x8_t pd[DY_ITERS], ph[HALO_ITERS];
+    // rows [first_row, 4) of the halo of tile (img, tx, ty): first_row = 0 at the start of a strip run, else 2
+    auto prefetch = [&](int l, bool full) {
+        const int ty = l % p.tiles_y, rest = l / p.tiles_y;
+        const int tx = rest % p.tiles_x, img = rest / p.tiles_x;
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        const bf16_t* dyb = p.dy + (size_t)img * p.H * p.W * p.ld_dy + co0 + piece_ch;
+        const bf16_t* xb = p.x + (size_t)img * p.H * p.W * p.ld_x + ci0 + piece_ch;
+#pragma unroll
+        for (int j = 0; j < DY_ITERS; ++j) {
+            const int pix = (tid >> 3) + j * (NTHREADS / 8);
+            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
+            if (oy < p.H && ox < p.W) pd[j] = *reinterpret_cast<const bf16x8_t*>(dyb + ((size_t)oy * p.W + ox) * p.ld_dy);
+            else pd[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        const int row0 = full ? 0 : 2;
+#pragma unroll
+        for (int j = 0; j < HALO_ITERS; ++j) {
+            if (j < HALO_ITERS2 || full) {
+                const int hp = (tid >> 3) + j * (NTHREADS / 8);
+                const int hy = hp / HALO_COLS, hx = hp - hy * HALO_COLS;
+                const int gy = ty0 - 1 + row0 + hy, gx = tx0 - 1 + hx;
+                if (row0 + hy < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                    ph[j] = *reinterpret_cast<const bf16x8_t*>(xb + ((size_t)gy * p.W + gx) * p.ld_x);
+                else ph[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
+    // k = parity of the tile's position in its strip run: halo row hr of the tile lives in ring slot (hr + 2k) & 3
+    auto commit = [&](int k, bool full) {
+#pragma unroll
+        for (int j = 0; j < DY_ITERS; ++j) {
+            const int pix = (tid >> 3) + j * (NTHREADS / 8);
+            *reinterpret_cast<bf16x8_t*>(dyl + sw(pix, piece_ch)) = pd[j];
+        }
+        const int row0 = full ? 0 : 2;
+#pragma unroll
+        for (int j = 0; j < HALO_ITERS; ++j) {
+            if (j < HALO_ITERS2 || full) {
+                const int hp = (tid >> 3) + j * (NTHREADS / 8);
+                const int hy = hp / HALO_COLS, hx = hp - hy * HALO_COLS;
+                const int slot = (row0 + hy + 2 * k) & 3;
+                if (row0 + hy < 4) *reinterpret_cast<bf16x8_t*>(xl + sw(slot * HP + hx, piece_ch)) = ph[j];
+            }
+        }
+    };
+
+    const int g = lane >> 4, li = lane & 15;
+    constexpr int NACC = M16 ? 36 : 9;
+    typedef typename std::conditional<M16, f32x4_t, f32x16_t>::type acc_t;
+    acc_t acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[t][r] = 0.f;
+
+    // transposing-read lane constants (see the version-1 kernel for the 32x32x16 pattern).  16x16x32: 16-lane group g
+    // covers pixels 8g + q (+4 for the second read) of a 32-pixel row, lane = 4q + p' addresses channels 4p'..4p'+3 of a
+    // 16-channel block; after the transpose lane j of the group holds channel j, pixels 8g..8g+7.
+    const int lpix = M16 ? 8 * g + (li >> 2) : 8 * (g >> 1) + (li >> 2);
+    const int lch = M16 ? 4 * (li & 3) : 16 * (g & 1) + 4 * (li & 3);
+    constexpr int NH = M16 ? 2 : 1;                      // 16-channel halves of the wave's 32 co / 32 ci
+    const unsigned dyl0 = (unsigned)(size_t)dyl, xl0 = (unsigned)(size_t)xl;
+    unsigned a_base[NH][2], b_base[3][NH][2];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            a_base[h][s] = dyl0 + sw(lpix + 4 * s, wa * 32 + 16 * h + lch);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) b_base[dx][h][s] = xl0 + sw(lpix + 4 * s + dx, wb * 32 + 16 * h + lch);
+        }
+
+    // Ring rotation without a second copy of the loop: halo row hr sits in slot (hr + 2k) & 3, i.e. two rows further on for
+    // hr < 2 and two rows back for hr >= 2 when k = 1.  The two byte offsets are added to the lane bases per tile.
+    auto compute = [&](int k) {
+        const int rot[2] = {k ? 2 * HP * 128 : 0, k ? -2 * HP * 128 : 0};
+        if constexpr (M16) {
+            bf16x8_t af[TH][2];
+            sfor<TH>([&](auto R_) { sfor<2>([&](auto H_) {
+                constexpr int r = R_, h = H_;
+                af[r][h] = tr_frag_u(a_base[h][0], a_base[h][1], (r * TW) * 128);
+            }); });
+            sfor<4>([&](auto HR_) {
+                constexpr int hr = HR_;
+                bf16x8_t bf[3][2];
+                sfor<3>([&](auto DX_) { sfor<2>([&](auto H_) {
+                    constexpr int dx = DX_, h = H_;
+                    bf[dx][h] = tr_frag_u(b_base[dx][h][0] + rot[hr >> 1], b_base[dx][h][1] + rot[hr >> 1], (hr * HP) * 128);
+                }); });
+                sfor<TH>([&](auto R_) {
+                    constexpr int r = R_, dy = hr - r;
+                    if constexpr (dy >= 0 && dy <= 2) {
+                        sfor<3>([&](auto DX_) { sfor<2>([&](auto HCO_) { sfor<2>([&](auto HCI_) {
+                            constexpr int dx = DX_, hco = HCO_, hci = HCI_;
+                            constexpr int a = ((dy * 3 + dx) * 2 + hco) * 2 + hci;
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][hco], bf[dx][hci], acc[a], 0, 0, 0);
+                        }); }); });
+                    }
+                });
+            });
+        } else {
+            sfor<2>([&](auto KX_) {
+                constexpr int kx = KX_;
+                bf16x8_t af[TH];
+                sfor<TH>([&](auto R_) { constexpr int r = R_; af[r] = tr_frag_u(a_base[0][0], a_base[0][1], (r * TW + kx * 16) * 128); });
+                sfor<4>([&](auto HR_) {
+                    constexpr int hr = HR_;
+                    bf16x8_t bf[3];
+                    sfor<3>([&](auto DX_) {
+                        constexpr int dx = DX_;
+                        bf[dx] = tr_frag_u(b_base[dx][0][0] + rot[hr >> 1], b_base[dx][0][1] + rot[hr >> 1], (hr * HP + kx * 16) * 128);
+                    });
+                    sfor<TH>([&](auto R_) {
+                        constexpr int r = R_, dy = hr - r;
+                        if constexpr (dy >= 0 && dy <= 2) {
+                            sfor<3>([&](auto DX_) {
+                                constexpr int dx = DX_;
+                                acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], bf[dx], acc[dy * 3 + dx], 0, 0, 0);
+                            });
+                        }
+                    });
+                });
+            });
+        }
+    };
+
+    int k = 0;
+    bool full = true;                                    // the tile about to be committed starts a strip run
+    if (l0 < l1) prefetch(l0, true);
+    for (int l = l0; l < l1; ++l) {
+        __syncthreads();
+        commit(k, full);
+        __syncthreads();
+        const bool next_full = (l + 1) % p.tiles_y == 0;        // the next tile is the first row of another strip
+        if (l + 1 < l1) prefetch(l + 1, next_full);
+        compute(k);
+        k = next_full ? 0 : (k ^ 1);
+        full = next_full;
+    }
+
+    // ---- partial block -> slab [split][co][tap][ci] ------------------------------------------------------
+    float* slab = p.ws + (size_t)split * p.Cout * 9 * p.Cin;
+    if constexpr (M16) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int hco = 0; hco < 2; ++hco)
+#pragma unroll
+                for (int hci = 0; hci < 2; ++hci)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = co0 + wa * 32 + hco * 16 + 4 * g + i;
+                        slab[((size_t)co * 9 + t) * p.Cin + ci0 + wb * 32 + hci * 16 + li] = acc[(t * 2 + hco) * 2 + hci][i];
+                    }
+    } else {
+        const int lx = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[((size_t)co * 9 + t) * p.Cin + ci0 + wb * 32 + lx] = acc[t][r];
+            }
+    }
+}
+
 // dw[co][ci][tap] = sum_s ws[s][co][tap][ci]
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout,
@@ -254,6 +478,14 @@ int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, 
     p.ci_blocks = d->cin / BI;
     p.pairs = pl.pairs; p.nsplit = pl.nsplit;
     p.xcd_order = pl.nsplit % 8 == 0;
+    // 3 (default): column strips with a rolling halo on the 16x16x32 MFMA; 2: the same on 32x32x16; 1: the first kernel
+    // (every tile stages its whole halo).  Measured on 6 x 256 x 512, 128 -> 128: 231 / 238 / 243 us.
+    static const int version = [] { const char* e = getenv("URESNET_WGRAD_V"); return e ? atoi(e) : 3; }();
+    if (version == 2 || version == 3) {
+        p.tiles_y = ur_cdiv(d->h, 2); p.tiles = d->n * p.tiles_x * p.tiles_y;
+        if (version == 3) hipLaunchKernelGGL((wgrad3x3_strip_kernel<true>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
+        else hipLaunchKernelGGL((wgrad3x3_strip_kernel<false>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
+    } else
     if (tile_rows() == 4) hipLaunchKernelGGL((wgrad3x3_tile_kernel<4, 1>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
     else hipLaunchKernelGGL((wgrad3x3_tile_kernel<2, 2>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
     if (int e = ur_check_launch("wgrad3x3_tile")) return e;
