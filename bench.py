@@ -46,6 +46,10 @@ def parse():
                          "the default brackets only the dominant kernel's launches")
     ap.add_argument("--per-shape", action="store_true", help="print per-(kernel, shape) conv timings to stderr")
     ap.add_argument("--per-shape-top", type=int, default=40)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole training step (forward, loss, backward, Adam, weight repack) as one HIP graph and time "
+                         "replays; the per-kernel events of `roofline` cannot be recorded inside a graph, so they are taken from "
+                         "the same number of eager steps run right after the timed region (the line says so)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="launch-path rehearsal without a GPU: the ranks rendezvous over gloo and push a small stand-in "
                          "torch.nn network through ddp.DataParallel; exercises spawning, bucketed all-reduce, the "
@@ -238,16 +242,31 @@ def main():
     for _ in range(args.warmup):
         loss, _ = step()
     fence()
-    if not args.no_kernel_timing:
-        ops.kernel_timings = []
-        ops.kernel_timing_tags = None if args.all_kernel_timing else {"tile_fwd", "tile_dgrad"}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step()
-    host_elapsed = time.perf_counter() - t0          # launches enqueued; the GPU is still working
-    fence()
-    elapsed = time.perf_counter() - t0
-    timings, ops.kernel_timings = ops.kernel_timings, None
+    graphed = None
+    if args.graph:
+        if ddp is not None:
+            raise SystemExit("--graph is a single-GPU option (the bucket hooks are host code)")
+        graphed = train.GraphedStep(train.seg_train_step, model, opt, x, y, warmup=1)
+        fence()
+
+    def timed_steps(fn, with_events):
+        if with_events and not args.no_kernel_timing:
+            ops.kernel_timings = []
+            ops.kernel_timing_tags = None if args.all_kernel_timing else {"tile_fwd", "tile_dgrad"}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = fn()
+        host = time.perf_counter() - t0              # launches enqueued; the GPU is still working
+        fence()
+        total = time.perf_counter() - t0
+        tm, ops.kernel_timings = ops.kernel_timings, None
+        return loss, host, total, tm
+
+    if graphed is None:
+        loss, host_elapsed, elapsed, timings = timed_steps(step, True)
+    else:
+        loss, host_elapsed, elapsed, _ = timed_steps(lambda: graphed(x, y), False)
+        _, _, eager_elapsed, timings = timed_steps(step, True)      # kernel events: eager re-run, outside the timed region
     final_loss = float(loss.item())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -300,7 +319,10 @@ def main():
                     "algorithmic_bytes_per_launch": (sum(dom_bytes) / len(dom_bytes)) if dom_bytes else None,
                     "launches": dom["launches"],
                     "avg_launch_ms": dom["avg_launch_ms"], "flops_per_launch": dom["flops_per_launch"],
-                    "time_share_of_step": dom["time_share_of_step"], "other_kernels": summary}
+                    "time_share_of_step": dom["time_share_of_step"], "other_kernels": summary,
+                    "timing_region": ("the timed steps" if graphed is None else
+                                      "the same %d steps run eagerly right after the timed graph replays (%.3f ms per step)"
+                                      % (args.steps, eager_elapsed / args.steps * 1e3))}
             for tag, (n, by, sec) in kernels.items():
                 if tag.startswith("hbm:") and n:
                     summary[tag[4:] + " (HBM-bound, algorithmic bytes)"] = {
@@ -335,7 +357,8 @@ def main():
                                    % (H, W),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "bn": "per-replica batch statistics", "final_loss": round(final_loss, 5),
-                       "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3)},
+                       "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
+                       "step_launch": "one HIP graph replay per step" if graphed is not None else "eager (about 460 launches per step)"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -211,3 +211,29 @@ def test_config4_full_resolution_1024x2048(pkg, oracle):
     assert _lib.query("ur_conv3x3_tile_supported", C.byref(d), 0) == 1
     d.in_ld = 8192                                   # a 64-channel window of an 8192-channel tensor: 2048 * 8192 = 2^24
     assert _lib.query("ur_conv3x3_tile_supported", C.byref(d), 0) == 0
+
+
+def test_config2_bf16_training_step_at_batch_32(pkg, oracle):
+    """Config 2 as stated: U_ResNet(100, 3) (U_ResNet_MiniImageNet.py:321) on a 32 x 3 x 224 x 224 batch, bf16, SGD lr 0.1
+    (CNN-MiniImageNet.py:36-51, 84-94).  Logits and loss of the first step against the oracle with bf16 storage emulation;
+    the second step's loss must be finite (lr 0.1 on random data may go up or down)."""
+    torch.manual_seed(0)
+    ref = oracle.MiniU_ResNet(100, 3).train()
+    oracle.emulate_bf16_storage(ref)
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(32, 3, 224, 224, generator=g)
+    y = torch.randint(0, 100, (32,), generator=g)
+    with torch.no_grad():
+        ro = ref(x)
+        rl = oracle.cls_loss(ro, y)
+    m = pkg.modules.U_ResNet_MiniImageNet.U_ResNet(100, 3).set_compute_dtype(torch.bfloat16)
+    m.load_state_dict(state0)
+    m.to(DEV).train()
+    opt = pkg.train.SGD(m.parameters(), lr=0.1)
+    loss, out = pkg.train.cls_train_step(m, opt, x.to(DEV), y.to(DEV))
+    print("\nconfig 2 bf16 B=32: logits rel-L2 %.2e, loss %.5f vs %.5f" % (rel_l2(out.float().cpu(), ro), loss.item(), rl.item()))
+    assert rel_l2(out.float().cpu(), ro) < 3e-2
+    assert abs(loss.item() - rl.item()) < 1e-2 * abs(rl.item())
+    loss2, _ = pkg.train.cls_train_step(m, opt, x.to(DEV), y.to(DEV))
+    assert torch.isfinite(loss2).item()
