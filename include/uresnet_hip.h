@@ -113,6 +113,16 @@ int ur_conv3x3_tile_fwd_affine(const void* x, const void* w_packed, void* y, con
  * add_ld = channel pitch of addend in elements (0 or cin: dense). */
 int ur_conv3x3_tile_dgrad_add(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
                               const ur_conv_desc* d, ur_stream_t s);
+/* Backward-data that also starts the backward pass of the BatchNorm(+ReLU) whose output the input tensor was
+ * (S/C:94-99, 140-144: conv -> BN -> ReLU -> conv).  dx (+ addend, as ur_conv3x3_tile_dgrad_add) is the gradient dz of
+ * that BatchNorm's output (the activation is ReLU); while the tile is still on chip the kernel reads the BatchNorm's input bn_y (and, for a
+ * residual block, its activated output bn_z, else NULL: the ReLU mask is rebuilt from bn_y) and writes per-tile partial
+ * sums partial[ur_conv3x3_tile_dgrad_stats_rows(d)][cin][2] = (sum g, sum g * x_hat), g = dz where the activation
+ * passed.  Folded by ur_bn_bwd_finalize they replace ur_bn_act_bwd_reduce: one pass over dz and bn_y less. */
+int ur_conv3x3_tile_dgrad_stats_rows(const ur_conv_desc* d);
+int ur_conv3x3_tile_dgrad_bnsums(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
+                                 const void* bn_y, int bn_y_ld, const void* bn_z, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, float* partial, const ur_conv_desc* d, ur_stream_t s);
 
 /* backward-weight counterpart (same contract as ur_conv2d_wgrad; needs 32 | cin and 32 | cout: 64 x 64-channel
  * blocks when both are multiples of 64, 32 x 32 blocks otherwise) */

@@ -728,6 +728,49 @@ def test_adam_keeps_a_step_count_per_parameter(pkg):
     assert float(sd[0]['step']) == 4.0 and float(sd[1]['step']) == 2.0
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 256, 512), (2, 64, 40, 72), (1, 32, 19, 45)])
+def test_bn_backward_sums_from_the_dgrad_epilogue(pkg, shape):
+    """conv -> BN -> ReLU -> conv chains (DoubleConv S/C:89-100, BasicBlock S/C:135-160): the backward-data kernel of the
+    second convolution emits the first BatchNorm's backward sums (ur_conv3x3_tile_dgrad_bnsums), so that BatchNorm runs no
+    reduction pass of its own.  Same gradients as the separate pass (fp32 sums in another order), the pass really is
+    skipped, and a second consumer of the intermediate tensor switches the shortcut off.  16-row, 8-row and ragged tiles."""
+    ops, B = pkg.ops, pkg.modules._blocks
+    n, c, h, w = shape
+    torch.manual_seed(4)
+    x0 = torch.randn(n, c, h, w, device=DEV)
+    g0 = torch.randn(n, c, h, w, device=DEV)
+
+    def run(block, fused, x_in=x0):
+        ops.fuse_bn_bwd_sums = fused
+        ops.kernel_timings, ops.kernel_timing_tags = [], {"hbm:bn_bwd_reduce"}
+        try:
+            block.zero_grad(set_to_none=True)
+            x = ops.as_activation(x_in, torch.bfloat16).detach().requires_grad_(True)
+            out = block(x)
+            out.backward(ops.as_activation(g0, torch.bfloat16))
+            reduces = len(ops.kernel_timings)
+        finally:
+            ops.fuse_bn_bwd_sums, ops.kernel_timings, ops.kernel_timing_tags = True, None, None
+        return host(pkg, x.grad), {k: p.grad.clone() for k, p in block.named_parameters()}, reduces
+
+    for block in (B.DoubleConv(c, c), B.BasicBlock(c, c), torch.nn.Sequential(B.BasicBlock(c, c), B.BasicBlock(c, c))):
+        block = block.to(DEV).train()
+        with torch.no_grad():
+            for m in block.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+        dx_a, gr_a, red_a = run(block, False)
+        dx_b, gr_b, red_b = run(block, True)
+        nbn = sum(isinstance(m, torch.nn.BatchNorm2d) for m in block.modules())
+        assert red_a == nbn
+        # DoubleConv: the middle BatchNorm is fused, the last one is not (nothing convolves its output here);
+        # BasicBlock: the middle one; two blocks in a row: both middle ones and the first block's output BatchNorm
+        assert red_b == red_a - {2: 1, 4: 3}[nbn], (nbn, red_a, red_b)
+        assert rel_l2(dx_b, dx_a) < 2e-3
+        for k in gr_a:
+            assert rel_l2(gr_b[k].cpu(), gr_a[k].cpu()) < 2e-3, k
+
+
 # ----------------------------------------------------------------------------- fused concatenation paths
 def test_conv3x3_into_channel_window(pkg):
     """ops.conv2d(out=window) for a bias-free 3x3 s1 p1 layer (the tile kernel): the result lands in the window with the

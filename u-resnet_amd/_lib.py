@@ -50,6 +50,8 @@ SIGNATURES = {
     "ur_conv3x3_tile_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad_add": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _vp]),
+    "ur_conv3x3_tile_dgrad_stats_rows": (_i, [_dp]),
+    "ur_conv3x3_tile_dgrad_bnsums": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_fwd_affine": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _dp, _vp]),
     "ur_wgrad3x3_tile_supported": (_i, [_dp]),
     "ur_wgrad3x3_tile_workspace": (_sz, [_dp]),

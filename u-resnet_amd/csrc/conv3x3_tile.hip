@@ -61,6 +61,12 @@ struct TileParams {
     const float* scale;   // [Cout] or null: result = acc * scale + shift (BatchNorm with fixed statistics, folded)
     const float* shift;
     int relu;             // clamp at zero after the affine map and the addend
+    // EPI 3 / 4 (backward-data whose result is the gradient dz of a BatchNorm(+ReLU) output): also emit that BatchNorm's
+    // backward partial sums per tile, stats[tile][c] = (sum g, sum g * x_hat) with g = dz where the activation passed
+    const bf16_t* bn_y;   // [N][H][W][ld_bny] the BatchNorm's input (raw convolution output)
+    const bf16_t* bn_z;   // [N][H][W][Cout] its activated output, or null: the ReLU mask is rebuilt from y
+    const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;
+    int ld_bny;
     int N, H, W, Cin, Cout;
     int ld_in, ld_out;
     int tiles_x, tiles_y, tiles;     // spatial tiles per image row / column / total (N * ty * tx)
@@ -130,7 +136,9 @@ __device__ __forceinline__ int halo_lds_offset(int hy, int hx, int piece) {
 }
 
 // EPI selects the epilogue at compile time (run-time options turn into hundreds of selects on the 128 accumulators):
-// 0 = rounded result (+ per-channel statistics), 1 = + addend, 2 = folded BatchNorm (scale, shift, optional residual, ReLU)
+// 0 = rounded result (+ per-channel statistics), 1 = + addend, 2 = folded BatchNorm (scale, shift, optional residual, ReLU),
+// 3 = rounded result + BatchNorm(+ReLU)-backward partial sums of the tensor it is the gradient of (ReLU mask rebuilt from
+// the BatchNorm's input), 4 = 3 with an addend, 5 / 6 = 3 / 4 with the mask taken from the stored activated tensor
 template <int R, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p) {
     using G = Geo<R>;
@@ -372,6 +380,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
             }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // EPI 3 / 4: a lane stores the same 8 channels (piece = lane & 7) of R * 4 pixels; it keeps their BatchNorm constants
+    // and the two running sums per channel in registers (the accumulators are dead once the tile is staged)
+    constexpr bool BNSUMS = EPI >= 3 && EPI <= 6, BN_ADD = EPI == 4 || EPI == 6, BN_FROM_Z = EPI == 5 || EPI == 6;
+    float bm[8], bis[8], bga[8], bbe[8], bs1[8], bs2[8];
+    if constexpr (BNSUMS) {
+        // the loads stay below this point: issued before the accumulators are staged they would need 32 more registers
+        // in a kernel that has none to spare
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const int c0 = nb * BN + (lane & 7) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool okc = c0 + k < p.Cout;
+            bm[k] = okc ? p.bn_mean[c0 + k] : 0.f; bis[k] = okc ? p.bn_invstd[c0 + k] : 0.f;
+            bga[k] = okc ? p.bn_gamma[c0 + k] : 0.f; bbe[k] = okc ? p.bn_beta[c0 + k] : 0.f;
+            bs1[k] = 0.f; bs2[k] = 0.f;
+        }
+    }
     auto store_piece = [&](int i, bool check) {
         const int idx = lane + 64 * i;
         const int pxl = idx >> 3, piece = idx & 7;
@@ -379,7 +405,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
         if (!check || (oy < p.H && ox < p.W && nb * BN + piece * 8 < p.Cout)) {
             const size_t pix = (size_t)(img * p.H + oy) * p.W + ox;
             bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ostage + pxl * OUT_PITCH + piece * 16);
-            if constexpr (EPI != 0) {
+            if constexpr (BNSUMS) {
+                const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(p.bn_y + pix * p.ld_bny + nb * BN + piece * 8);
+                bf16x8_t z8 = y8;
+                if constexpr (BN_FROM_Z) z8 = *reinterpret_cast<const bf16x8_t*>(p.bn_z + pix * p.Cout + nb * BN + piece * 8);
+                if constexpr (BN_ADD) {
+                    const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (bf16_t)((float)v[k] + (float)ad[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float xh = ((float)y8[k] - bm[k]) * bis[k];
+                    const float pre = BN_FROM_Z ? (float)z8[k] : xh * bga[k] + bbe[k];
+                    const float gv = pre > 0.f ? (float)v[k] : 0.f;
+                    bs1[k] += gv; bs2[k] += gv * xh;
+                }
+            }
+            if constexpr (EPI == 1 || EPI == 2) {
                 if (EPI == 1 || p.addend) {
                     const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
                     const bool relu = EPI == 2 && p.relu;
@@ -396,12 +439,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
     };
     if (interior && (nb + 1) * BN <= p.Cout) {
 #pragma unroll
-        for (int i = 0; i < R * 4; ++i) store_piece(i, false);
+        for (int i = 0; i < R * 4; ++i) {
+            store_piece(i, false);
+            // four pieces' loads in flight at a time: left alone the scheduler hoists all R * 4 * 2 loads and their
+            // conversions to the top and spills a hundred registers
+            if (BNSUMS && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < R * 4; ++i) store_piece(i, true);
+        for (int i = 0; i < R * 4; ++i) {
+            store_piece(i, true);
+            if (BNSUMS && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    if (EPI == 0 && p.stats) {
+    if constexpr (BNSUMS) {
+        // lanes with equal lane & 7 hold the same 8 channels: fold lane bits 3, 4, 5, then one row per wave as in EPI 0
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { bs1[k] += __shfl_xor(bs1[k], o, 64); bs2[k] += __shfl_xor(bs2[k], o, 64); }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { red[(wave * BN + lane * 8 + k) * 2] = bs1[k]; red[(wave * BN + lane * 8 + k) * 2 + 1] = bs2[k]; }
+        }
+    }
+    if ((EPI == 0 || BNSUMS) && p.stats) {
         __syncthreads();
         if (tid < BN && nb * BN + tid < p.Cout) {
             float* o = p.stats + ((size_t)tile * p.Cout + nb * BN + tid) * 2;
@@ -516,9 +579,13 @@ int pick_rows(const ur_conv_desc* d, bool dgrad) {
     return wgs4 >= 512 ? 4 : 2;
 }
 
+struct BnSums {          // the BatchNorm whose output gradient a backward-data launch produces (EPI 3 / 4)
+    const void* y; int ld_y; const void* z; const float *mean, *invstd, *gamma, *beta;
+};
+
 int launch(const void* src, const void* wpk, void* dst, float* stats, const ur_conv_desc* d, bool dgrad, hipStream_t st,
            const void* addend = nullptr, int add_ld = 0, const float* scale = nullptr, const float* shift = nullptr,
-           int relu = 0) {
+           int relu = 0, const BnSums* bn = nullptr) {
     const int R = pick_rows(d, dgrad);
     const int TH = 4 * R;
     TileParams p{};
@@ -532,10 +599,19 @@ int launch(const void* src, const void* wpk, void* dst, float* stats, const ur_c
     p.tiles = d->n * p.tiles_x * p.tiles_y;
     p.nblocks = ur_cdiv(p.Cout, BN);
     const int grid = ((p.tiles + 7) / 8 * 8) * p.nblocks;
-    const int epi = scale ? 2 : (addend ? 1 : 0);
+    int epi = scale ? 2 : (addend ? 1 : 0);
+    if (bn) {
+        p.bn_y = (const bf16_t*)bn->y; p.ld_bny = bn->ld_y; p.bn_z = (const bf16_t*)bn->z;
+        p.bn_mean = bn->mean; p.bn_invstd = bn->invstd; p.bn_gamma = bn->gamma; p.bn_beta = bn->beta;
+        epi = (bn->z ? 5 : 3) + (addend ? 1 : 0);
+    }
 #define UR_TILE_LAUNCH(RR, EE) hipLaunchKernelGGL((conv3x3_tile_kernel<RR, EE>), dim3(grid), dim3(NTHREADS), 0, st, p)
-    if (R == 4) { if (epi == 0) UR_TILE_LAUNCH(4, 0); else if (epi == 1) UR_TILE_LAUNCH(4, 1); else UR_TILE_LAUNCH(4, 2); }
-    else { if (epi == 0) UR_TILE_LAUNCH(2, 0); else if (epi == 1) UR_TILE_LAUNCH(2, 1); else UR_TILE_LAUNCH(2, 2); }
+#define UR_TILE_PICK(RR) switch (epi) { case 0: UR_TILE_LAUNCH(RR, 0); break; case 1: UR_TILE_LAUNCH(RR, 1); break; \
+                                         case 2: UR_TILE_LAUNCH(RR, 2); break; case 3: UR_TILE_LAUNCH(RR, 3); break; \
+                                         case 4: UR_TILE_LAUNCH(RR, 4); break; case 5: UR_TILE_LAUNCH(RR, 5); break; \
+                                         default: UR_TILE_LAUNCH(RR, 6); }
+    if (R == 4) { UR_TILE_PICK(4) } else { UR_TILE_PICK(2) }
+#undef UR_TILE_PICK
 #undef UR_TILE_LAUNCH
     return ur_check_launch("conv3x3_tile");
 }
@@ -583,6 +659,31 @@ long long ur_conv3x3_tile_pack_blocks(int cin, int cout, int dgrad) {
 
 int ur_conv3x3_tile_stats_rows(const ur_conv_desc* d) {
     return d ? d->n * ur_cdiv(d->h, 4 * pick_rows(d, false)) * ur_cdiv(d->w, TW) : 0;
+}
+
+int ur_conv3x3_tile_dgrad_stats_rows(const ur_conv_desc* d) {
+    return d ? d->n * ur_cdiv(d->h, 4 * pick_rows(d, true)) * ur_cdiv(d->w, TW) : 0;
+}
+
+int ur_conv3x3_tile_dgrad_bnsums(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
+                                 const void* bn_y, int bn_y_ld, const void* bn_z, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, float* partial, const ur_conv_desc* d, ur_stream_t s) {
+    if (int e = check(d, true)) return e;
+    UR_REQUIRE(dy && w_packed_dgrad && dx && bn_y && mean && invstd && gamma && beta && partial,
+               "conv3x3_tile_dgrad_bnsums: null pointer");
+    if (bn_y_ld == 0) bn_y_ld = d->cin;
+    UR_REQUIRE(bn_y_ld >= d->cin && bn_y_ld % 8 == 0 && ((uintptr_t)bn_y % 16) == 0 && (!bn_z || ((uintptr_t)bn_z % 16) == 0),
+               "conv3x3_tile_dgrad_bnsums: BatchNorm tensors must be 16-byte aligned with a pitch that is a multiple of 8");
+    UR_REQUIRE((long long)d->n * d->h * d->w * bn_y_ld < (1LL << 31), "conv3x3_tile_dgrad_bnsums: tensor exceeds 2^31 elements");
+    if (addend) {
+        if (add_ld == 0) add_ld = d->cin;
+        UR_REQUIRE(add_ld >= d->cin && add_ld % 8 == 0 && ((uintptr_t)addend % 16) == 0,
+                   "conv3x3_tile_dgrad_bnsums: addend pitch %d must be a multiple of 8 >= %d and the pointer 16-byte aligned", add_ld,
+                   d->cin);
+        UR_REQUIRE((long long)d->n * d->h * d->w * add_ld < (1LL << 31), "conv3x3_tile_dgrad_bnsums: addend exceeds 2^31 elements");
+    }
+    const BnSums bn{bn_y, bn_y_ld, bn_z, mean, invstd, gamma, beta};
+    return launch(dy, w_packed_dgrad, dx, partial, d, true, (hipStream_t)s, addend, add_ld, nullptr, nullptr, 0, &bn);
 }
 
 int ur_conv3x3_tile_fwd(const void* x, const void* w_packed, void* y, float* stats, const ur_conv_desc* d, ur_stream_t s) {

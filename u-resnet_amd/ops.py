@@ -417,6 +417,7 @@ class _Conv2d(Function):
             y = out[0]
         ctx.save_for_backward(x, weight)          # x: as the kernel saw it (channel-padded on the generic path)
         ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
+        ctx.bn_rec = getattr(x_in, "_ur_bn", None) if tile else None
         ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
         # alias of the input for a second consumer (the shortcut of a residual block): its gradient comes back to this
         # node and is added in the backward-data epilogue instead of by a separate add
@@ -459,8 +460,22 @@ class _Conv2d(Function):
                 add_ld = 0
                 if dalias is not None and dalias.dtype == x.dtype and dalias.data_ptr() % 16 == 0:
                     add_ld = _channel_pitch(dalias)
-                with _Timed("tile_dgrad", _conv_flops(d), d):
-                    if add_ld and add_ld % 8 == 0:
+                add_ok = bool(add_ld and add_ld % 8 == 0)
+                rec = ctx.bn_rec
+                fuse = (fuse_bn_bwd_sums and rec is not None and (dalias is None or add_ok)
+                        and tuple(rec.y.shape) == tuple(dx.shape) and rec.y.dtype == dx.dtype and _is_nhwc_dense(rec.y))
+                with _Timed("tile_dgrad_bn" if fuse else "tile_dgrad", _conv_flops(d), d):
+                    if fuse:
+                        # dx is the gradient of a BatchNorm+ReLU output: its backward sums come out of this kernel's epilogue
+                        rows = query("ur_conv3x3_tile_dgrad_stats_rows", C.byref(d))
+                        partial = torch.empty((rows, d.cin, 2), dtype=torch.float32, device=x.device)
+                        call("ur_conv3x3_tile_dgrad_bnsums", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(),
+                             dalias.data_ptr() if dalias is not None else None, add_ld if dalias is not None else 0,
+                             rec.y.data_ptr(), d.cin, _p(rec.z), rec.mean.data_ptr(), rec.invstd.data_ptr(),
+                             rec.gamma.data_ptr(), rec.beta.data_ptr(), partial.data_ptr(), C.byref(d), _stream())
+                        rec.partial, rec.dz_ptr, rec.dz_version = partial, dx.data_ptr(), dx._version
+                        dalias = None
+                    elif add_ok:
                         call("ur_conv3x3_tile_dgrad_add", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), dalias.data_ptr(), add_ld,
                              C.byref(d), _stream())
                         dalias = None
@@ -702,9 +717,25 @@ def gconv3x3(x, weight, want_stats=False):
 
 
 # ------------------------------------------------------------------------------ batch norm (+act, +residual)
+fuse_bn_bwd_sums = True     # False: BatchNorm backward always runs its own reduction pass (A/B comparisons)
+
+
+class _BNRecord:
+    """What the consumer of a BatchNorm+ReLU output needs to start that BatchNorm's backward pass: a 3x3 convolution whose
+    backward-data kernel produces the gradient dz of the output can emit the per-channel sums (sum g, sum g * x_hat) from
+    its epilogue (ur_conv3x3_tile_dgrad_bnsums) instead of a separate pass over dz and y.  The record travels as the
+    attribute `_ur_bn` of the output tensor; `partial` / `dz_ptr` / `dz_version` are filled in by the convolution's
+    backward and consumed by _BNAct.backward, which checks that the gradient it receives is that very tensor, unmodified
+    (a second consumer of z would have made autograd add to it or replace it)."""
+    __slots__ = ("y", "z", "gamma", "beta", "mean", "invstd", "partial", "dz_ptr", "dz_version")
+
+    def __init__(self):
+        self.partial = None
+
+
 class _BNAct(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, stats, running_mean, running_var, nbt, training, momentum, eps, act, out):
+    def forward(ctx, y, gamma, beta, residual, stats, running_mean, running_var, nbt, training, momentum, eps, act, out, rec):
         _require_gpu(y)
         n, c, h, w = y.shape
         rows = n * h * w
@@ -738,6 +769,12 @@ class _BNAct(Function):
         # the ReLU mask is recomputed from y in backward unless a residual was added before the activation
         ctx.save_for_backward(y, z if (act and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.act, ctx.eval, ctx.has_res = act, not training, residual is not None
+        ctx.rec = None
+        if (rec is not None and training and act == _lib.ACT_RELU and y.dtype == torch.bfloat16 and c % 8 == 0
+                and (out is None or via_dense) and y.data_ptr() % 16 == 0):
+            rec.y, rec.z = y, (z if residual is not None else None)
+            rec.gamma, rec.beta, rec.mean, rec.invstd = gamma, beta, mean, invstd
+            ctx.rec = rec
         if via_dense:
             if tuple(out[0].shape) != tuple(y.shape) or out[0].dtype != y.dtype or not _channel_pitch(out[0]):
                 raise RuntimeError("bn_act: `out` must be a channel window with y's shape and dtype")
@@ -757,12 +794,21 @@ class _BNAct(Function):
         dz_ld = _channel_pitch(dz) if (dz.is_cuda and dz.dtype == y.dtype) else 0
         if not dz_ld:
             dz, dz_ld = _g(dz), c
-        nparts = query("ur_bn_stats_rows", rows, c)
-        partial = torch.empty((nparts, c, 2), dtype=torch.float32, device=dev)
         tb = y.numel() * y.element_size()
-        with _Timed("hbm:bn_bwd_reduce", tb * (3 if z is not None else 2)):
-            call("ur_bn_act_bwd_reduce", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
-                 gamma.data_ptr(), beta.data_ptr(), ctx.act, _dt(y), rows, c, dz_ld, partial.data_ptr(), _stream())
+        rec = ctx.rec
+        if (rec is not None and rec.partial is not None and dz_ld == c and dz.data_ptr() == rec.dz_ptr
+                and dz._version == rec.dz_version):
+            # the backward-data kernel that produced dz has already summed g and g * x_hat per tile
+            partial, rec.partial = rec.partial, None
+            nparts = partial.shape[0]
+        else:
+            nparts = query("ur_bn_stats_rows", rows, c)
+            partial = torch.empty((nparts, c, 2), dtype=torch.float32, device=dev)
+            with _Timed("hbm:bn_bwd_reduce", tb * (3 if z is not None else 2)):
+                call("ur_bn_act_bwd_reduce", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
+                     gamma.data_ptr(), beta.data_ptr(), ctx.act, _dt(y), rows, c, dz_ld, partial.data_ptr(), _stream())
+        if rec is not None:
+            rec.partial = None
         sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
@@ -774,7 +820,7 @@ class _BNAct(Function):
             call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
                  gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres),
                  _dt(y), rows, c, dz_ld, _stream())
-        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU, out=None):
@@ -784,12 +830,16 @@ def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU, out=None):
     if training and bn.momentum is None:
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not implemented")
     track = training and bn.track_running_stats and bn.running_mean is not None
-    return _BNAct.apply(y, bn.weight, bn.bias, residual, stats if training else None,
-                        bn.running_mean if (track or not training) else None,
-                        bn.running_var if (track or not training) else None,
-                        bn.num_batches_tracked if track else None,
-                        training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, act,
-                        None if out is None else (out,))
+    rec = _BNRecord() if (fuse_bn_bwd_sums and training and torch.is_grad_enabled()) else None
+    z = _BNAct.apply(y, bn.weight, bn.bias, residual, stats if training else None,
+                     bn.running_mean if (track or not training) else None,
+                     bn.running_var if (track or not training) else None,
+                     bn.num_batches_tracked if track else None,
+                     training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, act,
+                     None if out is None else (out,), rec)
+    if rec is not None and getattr(rec, "y", None) is not None:
+        z._ur_bn = rec           # a following 3x3 convolution picks it up (see _BNRecord)
+    return z
 
 
 # ------------------------------------------------------------------------------ spatial ops
