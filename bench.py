@@ -46,6 +46,10 @@ def parse():
                          "the default brackets only the dominant kernel's launches")
     ap.add_argument("--per-shape", action="store_true", help="print per-(kernel, shape) conv timings to stderr")
     ap.add_argument("--per-shape-top", type=int, default=40)
+    ap.add_argument("--ddp-single", action="store_true",
+                    help="with --gpus 1: still wrap the model in ddp.DataParallel over a one-rank RCCL group, so that the hooks, "
+                         "the gradient buckets (filled in place by the backward-weight kernels) and the all-reduce launches run; "
+                         "the difference to the plain line is the per-step cost of the data-parallel machinery on one GPU")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole training step (forward, loss, backward, Adam, weight repack) as one HIP graph and time "
                          "replays; the per-kernel events of `roofline` cannot be recorded inside a graph, so they are taken from "
@@ -198,6 +202,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RCCL prints a version banner on the process's stdout when its first communicator comes up.  The contract is ONE
+    # JSON line on stdout: keep the real stdout aside for that line and point descriptor 1 at stderr meanwhile.
+    json_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if args.gpus != world:
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     torch.cuda.set_device(local)
@@ -205,6 +214,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    elif args.ddp_single:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1, device_id=dev)
     uresnet_amd._lib.load()
     if os.environ.get("URESNET_BATCH_PACK") == "0":          # A/B switches of two fusions
         ops.batch_repack = False
@@ -221,7 +232,7 @@ def main():
     torch.manual_seed(0)
     model = UResNetNewEUCB(19, 3, 64).set_compute_dtype(dtype).to(dev).train()
     opt = train.Adam(model.parameters(), lr=1e-4)
-    ddp = uresnet_amd.ddp.DataParallel(model) if world > 1 else None
+    ddp = uresnet_amd.ddp.DataParallel(model) if (world > 1 or args.ddp_single) else None
 
     B, H, W = args.batch, args.height, args.width
     g = torch.Generator().manual_seed(1234 + rank)
@@ -367,13 +378,19 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "bn": "per-replica batch statistics", "final_loss": round(final_loss, 5),
                        "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
+                       "data_parallel_wrapper": None if ddp is None else
+                       {"buckets": len(ddp.buckets), "bucket_order": ddp.bucket_order_source,
+                        "gradient_fraction_written_in_place_by_the_kernels":
+                            round(ddp.in_place_elems / max(1, ddp.in_place_elems + ddp.copied_elems), 4)},
                        "step_launch": "one HIP graph replay per step" if graphed is not None else "eager (about 460 launches per step)"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -79,6 +79,7 @@ class DataParallel:
         self._arrival = [] if reorder else None  # parameters in the order their gradients arrived (first step only)
         self._checked = False
         self.bucket_order_source = "reverse registration"
+        self.in_place_elems = self.copied_elems = 0      # gradient elements written into the buckets by the kernels / copied
 
     def _build(self, ordered):
         cap = int(self.bucket_mb * (1 << 20) / 4)
@@ -117,6 +118,9 @@ class DataParallel:
         slot = b.view(i)
         if p.grad.data_ptr() != slot.data_ptr():     # not written in place by the backward kernel
             slot.copy_(p.grad)
+            self.copied_elems += p.numel()
+        else:
+            self.in_place_elems += p.numel()
         b.had_grad[i] = True
         b.pending -= 1
         if b.pending == 0 and self._checked:         # the first step launches from finish(), after the consistency check
