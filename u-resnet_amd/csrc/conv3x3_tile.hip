@@ -438,12 +438,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
         }
     };
     if (interior && (nb + 1) * BN <= p.Cout) {
+        if constexpr (BNSUMS) {
+            // Batches: all global loads of a batch (BatchNorm input, activated tensor, addend) are issued before the first
+            // is used, so a batch pays one memory latency; the scheduling barriers keep the compiler from merging the
+            // batches (it then hoists every conversion to the top and spills a hundred registers).
+            constexpr int NP = R * 4, BT = (EPI == 3 && NP >= 16) ? 16 : (BN_ADD && R == 4 ? 4 : 8);
 #pragma unroll
-        for (int i = 0; i < R * 4; ++i) {
-            store_piece(i, false);
-            // four pieces' loads in flight at a time: left alone the scheduler hoists all R * 4 * 2 loads and their
-            // conversions to the top and spills a hundred registers
-            if (BNSUMS && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int b0 = 0; b0 < NP; b0 += BT) {
+                bf16x8_t yv[BT], zv[BT], av[BT];
+#pragma unroll
+                for (int j = 0; j < BT; ++j) {
+                    const int idx = lane + 64 * (b0 + j), pxl = idx >> 3, piece = idx & 7;
+                    const size_t pix = (size_t)(img * p.H + ty0 + wave * R + (pxl >> 5)) * p.W + tx0 + (pxl & 31);
+                    yv[j] = *reinterpret_cast<const bf16x8_t*>(p.bn_y + pix * p.ld_bny + nb * BN + piece * 8);
+                    if constexpr (BN_FROM_Z) zv[j] = *reinterpret_cast<const bf16x8_t*>(p.bn_z + pix * p.Cout + nb * BN + piece * 8);
+                    if constexpr (BN_ADD) av[j] = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < BT; ++j) {
+                    const int idx = lane + 64 * (b0 + j), pxl = idx >> 3, piece = idx & 7;
+                    const size_t pix = (size_t)(img * p.H + ty0 + wave * R + (pxl >> 5)) * p.W + tx0 + (pxl & 31);
+                    bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ostage + pxl * OUT_PITCH + piece * 16);
+                    if constexpr (BN_ADD) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = (bf16_t)((float)v[k] + (float)av[j][k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float xh = ((float)yv[j][k] - bm[k]) * bis[k];
+                        const float pre = BN_FROM_Z ? (float)zv[j][k] : xh * bga[k] + bbe[k];
+                        const float gv = pre > 0.f ? (float)v[k] : 0.f;
+                        bs1[k] += gv; bs2[k] += gv * xh;
+                    }
+                    *reinterpret_cast<bf16x8_t*>(p.y + pix * p.ld_out + nb * BN + piece * 8) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R * 4; ++i) store_piece(i, false);
         }
     } else {
 #pragma unroll
