@@ -14,6 +14,11 @@ import sys
 
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
+    # the tile kernel's epilogue variants are different kernels for this purpose: <R, 0|1|2> store the convolution result,
+    # <R, 3..6> also read a BatchNorm's input and emit its backward sums
+    m = re.search(r"conv3x3_tile_kernel<\d+, (\d+)>", name)
+    if m:
+        return "conv3x3_tile_kernel" if int(m.group(1)) <= 2 else "conv3x3_tile_kernel (BatchNorm-backward sums in the epilogue)"
     m = re.search(r"(\w+_kernel)", name)
     return m.group(1) if m else name[:40]
 
