@@ -771,6 +771,33 @@ def test_bn_backward_sums_from_the_dgrad_epilogue(pkg, shape):
             assert rel_l2(gr_b[k].cpu(), gr_a[k].cpu()) < 2e-3, k
 
 
+def test_training_steps_leave_no_reference_cycles(pkg):
+    """With Python's cycle collector switched off, device memory does not grow from step to step:
+    nothing the operators attach to tensors (BatchNorm records, aliases, channel windows) keeps a step's activations alive."""
+    import gc
+    M, train = pkg.modules.U_ResNet, pkg.train
+    torch.manual_seed(0)
+    m = M.UResNetNewEUCB(19, 3, 32).set_compute_dtype(torch.bfloat16).to(DEV).train()
+    opt = train.Adam(m.parameters(), lr=1e-4)
+    x = torch.randn(2, 3, 64, 96, device=DEV)
+    y = torch.randint(0, 19, (2, 64, 96), device=DEV)
+    for _ in range(2):
+        train.seg_train_step(m, opt, x, y)
+    gc.collect()
+    gc.disable()
+    try:
+        used = []
+        for _ in range(4):
+            loss, out = train.seg_train_step(m, opt, x, y)
+            del loss, out
+            torch.cuda.synchronize()
+            used.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    # two values alternate (the optimiser's pointer tables come from a ring of staging buffers); nothing accumulates
+    assert max(used[2:]) <= max(used[:2]), used
+
+
 # ----------------------------------------------------------------------------- fused concatenation paths
 def test_conv3x3_into_channel_window(pkg):
     """ops.conv2d(out=window) for a bias-free 3x3 s1 p1 layer (the tile kernel): the result lands in the window with the

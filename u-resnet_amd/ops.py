@@ -463,7 +463,8 @@ class _Conv2d(Function):
                 add_ok = bool(add_ld and add_ld % 8 == 0)
                 rec = ctx.bn_rec
                 fuse = (fuse_bn_bwd_sums and rec is not None and (dalias is None or add_ok)
-                        and tuple(rec.y.shape) == tuple(dx.shape) and rec.y.dtype == dx.dtype and _is_nhwc_dense(rec.y))
+                        and tuple(rec.y.shape) == tuple(dx.shape) and rec.y.dtype == dx.dtype and _is_nhwc_dense(rec.y)
+                        and (not rec.use_z or (_is_nhwc_dense(x) and x.data_ptr() % 16 == 0)))
                 with _Timed("tile_dgrad_bn" if fuse else "tile_dgrad", _conv_flops(d), d):
                     if fuse:
                         # dx is the gradient of a BatchNorm+ReLU output: its backward sums come out of this kernel's epilogue
@@ -471,7 +472,8 @@ class _Conv2d(Function):
                         partial = torch.empty((rows, d.cin, 2), dtype=torch.float32, device=x.device)
                         call("ur_conv3x3_tile_dgrad_bnsums", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(),
                              dalias.data_ptr() if dalias is not None else None, add_ld if dalias is not None else 0,
-                             rec.y.data_ptr(), d.cin, _p(rec.z), rec.mean.data_ptr(), rec.invstd.data_ptr(),
+                             rec.y.data_ptr(), d.cin, x.data_ptr() if rec.use_z else None, rec.mean.data_ptr(),
+                             rec.invstd.data_ptr(),
                              rec.gamma.data_ptr(), rec.beta.data_ptr(), partial.data_ptr(), C.byref(d), _stream())
                         rec.partial, rec.dz_ptr, rec.dz_version = partial, dx.data_ptr(), dx._version
                         dalias = None
@@ -726,8 +728,10 @@ class _BNRecord:
     its epilogue (ur_conv3x3_tile_dgrad_bnsums) instead of a separate pass over dz and y.  The record travels as the
     attribute `_ur_bn` of the output tensor; `partial` / `dz_ptr` / `dz_version` are filled in by the convolution's
     backward and consumed by _BNAct.backward, which checks that the gradient it receives is that very tensor, unmodified
-    (a second consumer of z would have made autograd add to it or replace it)."""
-    __slots__ = ("y", "z", "gamma", "beta", "mean", "invstd", "partial", "dz_ptr", "dz_version")
+    (a second consumer of z would have made autograd add to it or replace it).  The record does not reference the output
+    tensor itself (the tensor references the record): `use_z` tells the consumer that the ReLU mask must come from the
+    stored output, which the consumer holds anyway as its saved input."""
+    __slots__ = ("y", "use_z", "gamma", "beta", "mean", "invstd", "partial", "dz_ptr", "dz_version")
 
     def __init__(self):
         self.partial = None
@@ -772,7 +776,7 @@ class _BNAct(Function):
         ctx.rec = None
         if (rec is not None and training and act == _lib.ACT_RELU and y.dtype == torch.bfloat16 and c % 8 == 0
                 and (out is None or via_dense) and y.data_ptr() % 16 == 0):
-            rec.y, rec.z = y, (z if residual is not None else None)
+            rec.y, rec.use_z = y, residual is not None
             rec.gamma, rec.beta, rec.mean, rec.invstd = gamma, beta, mean, invstd
             ctx.rec = rec
         if via_dense:
