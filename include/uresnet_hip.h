@@ -94,7 +94,8 @@ int ur_conv3x3_tile_supported(const ur_conv_desc* d, int dgrad);
 size_t ur_conv3x3_tile_packed_elems(const ur_conv_desc* d);
 int ur_conv3x3_tile_pack_weight(const float* w, void* packed, const ur_conv_desc* d, int dgrad, ur_stream_t s);
 /* the same for many layers in one launch (after an optimiser step every layer's image is stale at once):
- * table = device array of `entries` rows {w, packed, cin, cout, dgrad, first_block}, six 64-bit words each, where
+ * table = device array of `entries` rows {w, packed, cin, cout, dgrad (bit 1: piece order of ur_conv3x3_wide_*), first_block},
+ * six 64-bit words each, where
  * first_block = the sum of ur_conv3x3_tile_pack_blocks over the rows before it; total_blocks = that sum over all rows */
 long long ur_conv3x3_tile_pack_blocks(int cin, int cout, int dgrad);
 int ur_conv3x3_tile_pack_weights_multi(const long long* table, int entries, long long total_blocks, ur_stream_t s);
@@ -123,6 +124,29 @@ int ur_conv3x3_tile_dgrad_stats_rows(const ur_conv_desc* d);
 int ur_conv3x3_tile_dgrad_bnsums(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
                                  const void* bn_y, int bn_y_ld, const void* bn_z, const float* mean, const float* invstd,
                                  const float* gamma, const float* beta, float* partial, const ur_conv_desc* d, ur_stream_t s);
+
+/* ---------------------------------------------------------------- 3x3 / stride 1 / pad 1, bf16: 128-channel kernel
+ * Same contract and results (to bf16 rounding of a differently ordered fp32 sum) as ur_conv3x3_tile_fwd / _dgrad for the
+ * layers of S/C:94,97,140,143 that produce a multiple of 128 channels and reduce over a multiple of 32: one persistent
+ * 8-wave workgroup per CU, operands staged by LDS-DMA, 16x16x32 MFMA.  Its weight image has its own piece order
+ * (ur_conv3x3_wide_pack_weight; same size as the tile kernel's; a row of ur_conv3x3_tile_pack_weights_multi builds it
+ * when bit 1 of the row's dgrad word is set).  ur_conv3x3_wide_preferred tells whether it is the faster of the two for
+ * the shape.  stats: [ur_conv3x3_wide_stats_rows(d)][cout][2] per-tile partial sums as for the tile kernel. */
+int ur_conv3x3_wide_supported(const ur_conv_desc* d, int dgrad);
+int ur_conv3x3_wide_preferred(const ur_conv_desc* d, int dgrad);
+size_t ur_conv3x3_wide_packed_elems(const ur_conv_desc* d);
+int ur_conv3x3_wide_pack_weight(const float* w, void* packed, const ur_conv_desc* d, int dgrad, ur_stream_t s);
+int ur_conv3x3_wide_stats_rows(const ur_conv_desc* d);
+int ur_conv3x3_wide_fwd(const void* x, const void* w_packed, void* y, float* stats, const ur_conv_desc* d, ur_stream_t s);
+int ur_conv3x3_wide_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const ur_conv_desc* d, ur_stream_t s);
+/* as ur_conv3x3_tile_dgrad_add, and as ur_conv3x3_tile_dgrad_bnsums without addend and with the ReLU mask rebuilt from bn_y
+ * (the residual-block forms, with bn_z or an addend, stay with the tile kernel);
+ * partial[ur_conv3x3_wide_stats_rows(d)][cin][2] */
+int ur_conv3x3_wide_dgrad_add(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
+                              const ur_conv_desc* d, ur_stream_t s);
+int ur_conv3x3_wide_dgrad_bnsums(const void* dy, const void* w_packed_dgrad, void* dx, const void* bn_y, int bn_y_ld,
+                                 const float* mean, const float* invstd, const float* gamma, const float* beta, float* partial,
+                                 const ur_conv_desc* d, ur_stream_t s);
 
 /* backward-weight counterpart (same contract as ur_conv2d_wgrad; needs 32 | cin and 32 | cout: 64 x 64-channel
  * blocks when both are multiples of 64, 32 x 32 blocks otherwise) */

@@ -96,6 +96,37 @@ def main():
             if res["tile"] is not None and res["wide"] is not None:
                 line += "  | max|wide-tile| %.2e" % (res["wide"][0].float() - res["tile"][0].float()).abs().max().item()
         print(line, flush=True)
+        # backward-data epilogue variants (addend; BatchNorm-backward sums with the mask rebuilt from the BatchNorm's input)
+        if lib.ur_conv3x3_wide_supported(C.byref(d), 1):
+            dyt = torch.randn(n, h, w, cout, device=dev).to(torch.bfloat16)
+            add = torch.randn(n, h, w, cin, device=dev).to(torch.bfloat16)
+            bny = torch.randn(n, h, w, cin, device=dev).to(torch.bfloat16)
+            mean, inv = torch.randn(cin, device=dev) * 0.1, torch.rand(cin, device=dev) + 0.5
+            gam, bet = torch.randn(cin, device=dev), torch.randn(cin, device=dev) * 0.3
+            out, tms = {}, {}
+            for name in ("tile", "wide"):
+                wpk = torch.empty(getattr(lib, "ur_conv3x3_%s_packed_elems" % name)(C.byref(d)), dtype=torch.bfloat16, device=dev)
+                assert getattr(lib, "ur_conv3x3_%s_pack_weight" % name)(vp(wt), vp(wpk), C.byref(d), 1, st) == 0
+                dx1 = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+                dx2 = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+                rows = (lib.ur_conv3x3_tile_dgrad_stats_rows if name == "tile" else lib.ur_conv3x3_wide_stats_rows)(C.byref(d))
+                part = torch.zeros(rows, cin, 2, device=dev)
+                f_add = lambda: getattr(lib, "ur_conv3x3_%s_dgrad_add" % name)(vp(dyt), vp(wpk), vp(dx1), vp(add), cin, C.byref(d), st)  # noqa: E731
+                if name == "tile":
+                    f_bn = lambda: lib.ur_conv3x3_tile_dgrad_bnsums(vp(dyt), vp(wpk), vp(dx2), None, 0, vp(bny), cin, None, vp(mean),  # noqa: E731
+                                                                    vp(inv), vp(gam), vp(bet), vp(part), C.byref(d), st)
+                else:
+                    f_bn = lambda: lib.ur_conv3x3_wide_dgrad_bnsums(vp(dyt), vp(wpk), vp(dx2), vp(bny), cin, vp(mean), vp(inv), vp(gam),  # noqa: E731
+                                                                    vp(bet), vp(part), C.byref(d), st)
+                assert f_add() == 0 and f_bn() == 0
+                torch.cuda.synchronize()
+                out[name] = (dx1, dx2, part.sum(0))
+                tms[name] = (timed(f_add), timed(f_bn))
+            t_, w_ = out["tile"], out["wide"]
+            print("    dgrad+add  tile %7.1f us wide %7.1f us  max|diff| %.2e   dgrad+bnsums tile %7.1f us wide %7.1f us  max|dx diff| %.2e  sums rel %.1e" % (
+                tms["tile"][0] * 1e3, tms["wide"][0] * 1e3, (t_[0].float() - w_[0].float()).abs().max().item(),
+                tms["tile"][1] * 1e3, tms["wide"][1] * 1e3, (t_[1].float() - w_[1].float()).abs().max().item(),
+                ((t_[2] - w_[2]).norm() / t_[2].norm()).item()), flush=True)
 
 
 if __name__ == "__main__":

@@ -51,6 +51,15 @@ SIGNATURES = {
     "ur_conv3x3_tile_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad_add": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _vp]),
     "ur_conv3x3_tile_dgrad_stats_rows": (_i, [_dp]),
+    "ur_conv3x3_wide_supported": (_i, [_dp, _i]),
+    "ur_conv3x3_wide_preferred": (_i, [_dp, _i]),
+    "ur_conv3x3_wide_packed_elems": (_sz, [_dp]),
+    "ur_conv3x3_wide_pack_weight": (_i, [_vp, _vp, _dp, _i, _vp]),
+    "ur_conv3x3_wide_stats_rows": (_i, [_dp]),
+    "ur_conv3x3_wide_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
+    "ur_conv3x3_wide_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
+    "ur_conv3x3_wide_dgrad_add": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _vp]),
+    "ur_conv3x3_wide_dgrad_bnsums": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_dgrad_bnsums": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv3x3_tile_fwd_affine": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _dp, _vp]),
     "ur_wgrad3x3_tile_supported": (_i, [_dp]),

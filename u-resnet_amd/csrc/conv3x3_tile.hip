@@ -518,8 +518,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
 constexpr int PACK_BLOCK = BN * KC * 9;
 constexpr int PACK_ROW = KC * 9 + 1;              // forward staging rows are 144 floats: one pad word makes the lane stride odd
 constexpr int PACK_TILE = BN * PACK_ROW;          // (an even stride of 144 words put 32 lanes on two LDS banks)
+// `wide` selects the piece order of the 128-channel kernel (conv3x3_wide.hip): the same 64 x 16 x 9 source block, its
+// pieces scattered in runs of 256 bytes: piece (row r, k-half kh, tap) of block (nb, chunk) goes to
+// [nb / 2][chunk / 2][dx][dy][nb & 1][r / 16][lane = (r & 15) + 16 * (2 * (chunk & 1) + kh)].
 __device__ __forceinline__ void pack_tile_weights_body(const float* __restrict__ w, bf16_t* __restrict__ dst, int cin, int cout,
-                                                        int dgrad, int first, int step, float* tile) {
+                                                        int dgrad, int wide, int first, int step, float* tile) {
     const int rows = dgrad ? cin : cout;      // channels produced by the kernel
     const int red = dgrad ? cout : cin;       // channels reduced over
     const int chunks = red / KC;
@@ -557,16 +560,22 @@ __device__ __forceinline__ void pack_tile_weights_body(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 o[j] = (bf16_t)(dgrad ? tile[(k0 + j) * (BN * 9) + n * 9 + (8 - tap)] : tile[n * PACK_ROW + (k0 + j) * 9 + tap]);
-            *reinterpret_cast<bf16x8_t*>(dst + ((size_t)blk * (PACK_BLOCK / 8) + pi) * 8) = o;
+            size_t piece = (size_t)blk * (PACK_BLOCK / 8) + pi;
+            if (wide) {
+                const int dyk = tap / 3, dxk = tap - dyk * 3;
+                piece = ((((((size_t)(nb >> 1) * (chunks >> 1) + (chunk >> 1)) * 3 + dxk) * 3 + dyk) * 2 + (nb & 1)) * 4 + (n >> 4)) * 64 +
+                        (n & 15) + 16 * (2 * (chunk & 1) + (lane >> 5));
+            }
+            *reinterpret_cast<bf16x8_t*>(dst + piece * 8) = o;
         }
         __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(256) void pack_tile_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int cin,
-                                                                int cout, int dgrad) {
+                                                                int cout, int dgrad, int wide) {
     __shared__ float tile[PACK_TILE];
-    pack_tile_weights_body(w, dst, cin, cout, dgrad, blockIdx.x, gridDim.x, tile);
+    pack_tile_weights_body(w, dst, cin, cout, dgrad, wide, blockIdx.x, gridDim.x, tile);
 }
 
 // Many layers in one launch: table[e] = {w, dst, cin, cout, dgrad, first block} (64-bit words).  One workgroup per
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(256) void pack_tile_weights_multi_kernel(const long
     }
     const long long* row = table + 6 * (long long)lo;
     pack_tile_weights_body(reinterpret_cast<const float*>(row[0]), reinterpret_cast<bf16_t*>(row[1]), (int)row[2], (int)row[3],
-                           (int)row[4], (int)(b - row[5]), 1 << 30, tile);
+                           (int)row[4] & 1, ((int)row[4] >> 1) & 1, (int)(b - row[5]), 1 << 30, tile);
 }
 
 int check(const ur_conv_desc* d, bool dgrad) {
@@ -652,6 +661,14 @@ int launch(const void* src, const void* wpk, void* dst, float* stats, const ur_c
 
 }  // namespace
 
+// One layer's image in either piece order (shared with conv3x3_wide.hip, whose caller has checked the shape).
+int ur_pack3x3_image(const float* w, void* packed, int cin, int cout, int dgrad, int wide, hipStream_t s) {
+    const long long total = (long long)cin * cout * 9;
+    hipLaunchKernelGGL(pack_tile_weights_kernel, dim3(ur_grid_1d(total, PACK_BLOCK, 2048)), dim3(256), 0, s, w, (bf16_t*)packed, cin,
+                       cout, dgrad, wide);
+    return ur_check_launch("pack_tile_weights");
+}
+
 extern "C" {
 
 int ur_conv3x3_tile_supported(const ur_conv_desc* d, int dgrad) {
@@ -672,10 +689,7 @@ size_t ur_conv3x3_tile_packed_elems(const ur_conv_desc* d) {
 int ur_conv3x3_tile_pack_weight(const float* w, void* packed, const ur_conv_desc* d, int dgrad, ur_stream_t s) {
     if (int e = check(d, dgrad != 0)) return e;
     UR_REQUIRE(w && packed, "conv3x3_tile_pack_weight: null pointer");
-    const long long total = (long long)d->cin * d->cout * 9;
-    hipLaunchKernelGGL(pack_tile_weights_kernel, dim3(ur_grid_1d(total, PACK_BLOCK, 2048)), dim3(256), 0, (hipStream_t)s, w,
-                       (bf16_t*)packed, d->cin, d->cout, dgrad != 0);
-    return ur_check_launch("pack_tile_weights");
+    return ur_pack3x3_image(w, packed, d->cin, d->cout, dgrad != 0, 0, (hipStream_t)s);
 }
 
 int ur_conv3x3_tile_pack_weights_multi(const long long* table, int entries, long long total_blocks, ur_stream_t s) {

@@ -20,7 +20,6 @@
 //     across item boundaries, so only the first item pays the fill latency; the epilogue stages one output row per wave
 //     at a time in the halo buffer that has just been consumed.
 #include "ur_common.h"
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -48,9 +47,12 @@ struct WideParams {
     const bf16_t* x;      // [N][H][W][ld_in]
     const bf16_t* wpk;    // [Cout/128][Cin/32][dx][dy][half][n][lane][8]
     bf16_t* y;            // [N][H][W][ld_out]
-    float* stats;         // [tiles][Cout][2] or null
-    int N, H, W, Cin, Cout, ld_in, ld_out;
-    int dbg;
+    float* stats;         // [tiles][Cout][2] or null: per-tile sums (EPI 0: of y and y^2; EPI 3..6: of the BatchNorm backward pass)
+    const bf16_t* addend; // EPI 1, 4, 6: [N][H][W][ld_add], added to the result before it is stored
+    const bf16_t* bn_y;   // EPI 3..6: input of the BatchNorm whose output gradient this launch produces, [N][H][W][ld_bny]
+    const bf16_t* bn_z;   // EPI 5, 6: that BatchNorm's activated output, dense [N][H][W][Cout] (the ReLU mask is z > 0)
+    const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+    int N, H, W, Cin, Cout, ld_in, ld_out, ld_add, ld_bny;
     int tiles_x, tiles_y, tiles, tiles8, nblocks, items;       // items = tiles8 * nblocks (tiles rounded up to 8)
 };
 
@@ -101,6 +103,10 @@ struct Cursor {
     bool valid;
 };
 
+// EPI selects the epilogue at compile time: 0 = store (+ statistics of the fp32 results when p.stats), 1 = + addend,
+// 3 = BatchNorm-backward sums with the ReLU mask rebuilt from bn_y, 4 = 3 + addend, 5 = sums with the mask from bn_z,
+// 6 = 5 + addend (the numbering of conv3x3_tile.hip).
+template <int EPI>
 __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[WT_LDS];
     __shared__ float red[8][64][2];
@@ -153,18 +159,16 @@ __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams 
     };
     // Halo of the slice of cursor c into halo buffer `buf`.  Wave w owns wave-instructions w, w + 8, ...; lane l of
     // instruction q writes 16-byte slot s = 64 q + l: pixel s >> 2 (row-major over 18 x 34), physical piece s & 3, which
-    // holds channel piece (s & 3) ^ ((column >> 1) & 3).  h_off = byte offset from the halo's first pixel, h_yx = (row, column)
-    // for the bounds test of a tile on the image border (its padding pixels are fetched from a block of zeros).
+    // holds channel piece (s & 3) ^ ((column >> 1) & 3).  h_off = byte offset from the halo's first pixel; a tile on the image
+    // border tests each slot's (row, column) and fetches its padding pixels from a block of zeros.
     auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
     const int halo_count = wave == 7 ? WT_HALO_PER_WAVE - 1 : WT_HALO_PER_WAVE;   // DMA instructions of this wave per halo
     unsigned h_off[WT_HALO_PER_WAVE];
-    int h_yx[WT_HALO_PER_WAVE];
 #pragma unroll
     for (int j = 0; j < WT_HALO_PER_WAVE; ++j) {
         const int s = (wave + 8 * j) * 64 + lane;
         const int pix = s >> 2, hy = pix / WT_HW, hx = pix - hy * WT_HW;
         h_off[j] = (unsigned)(((hy * p.W + hx) * p.ld_in + (((s & 3) ^ ((hx >> 1) & 3)) << 3)) * 2);
-        h_yx[j] = s < WT_HALO_SLOTS ? (hy | (hx << 8)) : -1;
     }
     auto issue_halo = [&](const Cursor& c, int buf) {
         const unsigned dst0 = lds0 + buf * WT_HALO_BYTES + wave * 1024;
@@ -172,16 +176,20 @@ __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams 
         const unsigned char* org = reinterpret_cast<const unsigned char*>(p.x) +
                                    (((long long)(c.img * p.H + c.ty0 - 1) * p.W + c.tx0 - 1) * p.ld_in + c.chunk * WT_KC) * 2;
         const bool inside = c.ty0 >= 1 && c.tx0 >= 1 && c.ty0 + WT_TH + 1 <= p.H && c.tx0 + WT_TW + 1 <= p.W;
+        const int l = opaque(lane);
         wt_for<WT_HALO_PER_WAVE>([&](auto J_) {
             constexpr int j = J_;
             if (wave + 8 * j < WT_HALO_INSTR) {              // uniform: the waits below count the instructions issued
-                if (h_yx[j] >= 0) {
+                const int s = (wave + 8 * j) * 64 + l;
+                if (s < WT_HALO_SLOTS) {
                     if (inside) {
                         wt_dma16_s(h_off[j], org, dst0 + j * 8192);
-                    } else {
-                        const int gy = c.ty0 - 1 + (h_yx[j] & 255), gx = c.tx0 - 1 + (h_yx[j] >> 8);
+                    } else {                                 // tile on the image border: (row, column) of the slot once more
+                        const int pix = s >> 2, hy = pix / WT_HW, hx = pix - hy * WT_HW;
+                        const int gy = c.ty0 - 1 + hy, gx = c.tx0 - 1 + hx;
                         const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                        wt_dma16(ok ? (const void*)(org + h_off[j]) : (const void*)wt_zero_block, dst0 + j * 8192);
+                        // (opaque: the 64-bit form of the offset must not become a second loop-invariant register pair)
+                        wt_dma16(ok ? (const void*)(org + (unsigned)opaque((int)h_off[j])) : (const void*)wt_zero_block, dst0 + j * 8192);
                     }
                 }
             }
@@ -239,7 +247,6 @@ __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams 
     Cursor cur, pw, ph;
     start(cur);
     if (!cur.valid) return;
-    if (p.dbg & 16) for (int k = ((blockIdx.x >> 3) & 7) * (p.dbg >> 8); k > 0; --k) __builtin_amdgcn_s_sleep(32);
     pw = cur; ph = cur;
     // fill: halo of the first slice, weight thirds 0 and 1
     issue_halo(ph, 0);
@@ -255,11 +262,10 @@ __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams 
     // released -- and the LDS reads of third s+1's first operands, which the two remaining MFMA phases cover.  A stage lands
     // two thirds (weights) or three (halo) after it is issued; the barrier of third s admits in flight only what was issued
     // after the operands third s+1 needs (loads and stores retire in issue order).
-    const bool dma_on = !(p.dbg & 2), w_on = dma_on && !(p.dbg & 8), h_on = dma_on && !(p.dbg & 4);
     bool w_issued = false, h_issued = false;       // the latest weight stage / the halo stage for the next slice went out
     int stores_in_flight = 0;                      // output stores of the previous item, when their count is known
-    if (pw.valid && w_on) { issue_weights(pw, 2); next_third(pw); w_issued = true; }
-    if (ph.valid && h_on) { issue_halo(ph, 1); next_slice(ph); h_issued = true; }
+    if (pw.valid) { issue_weights(pw, 2); next_third(pw); w_issued = true; }
+    if (ph.valid) { issue_halo(ph, 1); next_slice(ph); h_issued = true; }
     {
         const unsigned ab[2] = {a0[0][0], a0[0][1]};
         read_w(I0{}, b0); read_row(I0{}, ab); read_w(I1{}, b0); read_w(I2{}, b0);
@@ -276,7 +282,10 @@ __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams 
         const int item_tile_img = cur.img, item_ty0 = cur.ty0, item_tx0 = cur.tx0, item_nb = cur.nb;
         const int item_id = cur.item;
         bool halo_deferred = false;
-        for (int chunk = 0; chunk < chunks; ++chunk, ++slice) {
+        // one 32-channel slice = three thirds; the item's last slice is a copy of the code whose last third leaves the reads
+        // of the next third's operands to after the epilogue
+        auto do_slice = [&](int chunk, auto LAST_) {
+            constexpr bool LAST = LAST_;
             const unsigned hoff = (slice & 1) * WT_HALO_BYTES;
             const bool h_this_slice = h_issued;    // the halo stage that went out for this slice's successor
             wt_for<3>([&](auto G_) {
@@ -306,29 +315,36 @@ __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams 
                 }
                 __builtin_amdgcn_s_barrier();
                 // stage for the next third
-                w_issued = pw.valid && w_on;
+                w_issued = pw.valid;
                 if (w_issued) { issue_weights(pw, slot); next_third(pw); }
                 if constexpr (g == 2) {
-                    h_issued = ph.valid && h_on;
+                    h_issued = ph.valid;
                     if (h_issued) {
-                        if (chunk + 1 < chunks) { issue_halo(ph, slice & 1); next_slice(ph); }
+                        if constexpr (!LAST) { issue_halo(ph, slice & 1); next_slice(ph); }
                         else halo_deferred = true;             // the epilogue stages its rows in that buffer first
                     }
                 }
-                {
+                // The two remaining MFMA phases, with the LDS reads of the next third's first operands issued in between.  After
+                // the item's last third the reads wait until the epilogue is done: it needs the registers.
+                if constexpr (g == 2 && LAST) {
+                    mma(I1{}, I4{}); mma(I2{}, I4{}); mma(I2{}, I5{});
+                } else {
                     const unsigned bbn = b0 + ((step + 1) % 3) * WT_THIRD_BYTES;
                     const unsigned hoffn = g == 2 ? ((slice + 1) & 1) * WT_HALO_BYTES : hoff;
                     const unsigned abn[2] = {a0[(g + 1) % 3][0] + hoffn, a0[(g + 1) % 3][1] + hoffn};
                     read_w(I0{}, bbn); read_row(I0{}, abn);
-                        mma(I1{}, I4{}); mma(I2{}, I4{});
-                        read_w(I1{}, bbn);
-                        mma(I2{}, I5{});
-                        read_w(I2{}, bbn);
+                    mma(I1{}, I4{}); mma(I2{}, I4{});
+                    read_w(I1{}, bbn);
+                    mma(I2{}, I5{});
+                    read_w(I2{}, bbn);
                 }
                 ++step;
             });
             next_slice(cur);           // (cur.third stays 0: the thirds are unrolled above)
-        }
+            ++slice;
+        };
+        for (int chunk = 0; chunk + 1 < chunks; ++chunk) do_slice(chunk, std::false_type{});
+        do_slice(chunks - 1, std::true_type{});
 
         // ---- epilogue: one output row per wave at a time through the halo buffer the last slice has released ----------
         // The weights are the MFMA's row operand, so a lane holds four consecutive channels (n * 16 + 4 * kq + i) of one
@@ -396,12 +412,116 @@ __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams 
                     }
             }
         };
-        if (!(p.dbg & 1)) {
+        // Epilogues that read other tensors at the output's positions.  After the row is staged a lane holds 8 consecutive
+        // channels (piece = lane & 7) of pixels (lane >> 3) + 8 k: the layout of its 16-byte stores, and of 16-byte loads
+        // of the addend and of the BatchNorm's input / output.  The loads of row a + 1 are issued before row a is worked on.
+        auto epilogue_x = [&](auto FULL_) {
+            constexpr bool FULL = FULL_;
+            constexpr bool BNS = EPI >= 3, ADD = EPI == 1 || EPI == 4 || EPI == 6, FROMZ = EPI == 5 || EPI == 6;
+            const int el = opaque(lane), em = el & 15, ekq = el >> 4, piece = el & 7, pr = el >> 3;
+            unsigned char* ostage = lds + ((slice - 1) & 1) * WT_HALO_BYTES + wave * WT_STAGE_BYTES;
+            unsigned char* wr = ostage + em * WT_OUT_PITCH + ekq * 8;
+            const unsigned char* rd = ostage + pr * WT_OUT_PITCH + piece * 16;
+            const int cb = item_nb * WT_BN + ch * 64;            // first channel of this wave's half
+            const unsigned lane_out = (unsigned)((pr * p.ld_out + piece * 8) * 2), lane_add = (unsigned)((pr * p.ld_add + piece * 8) * 2);
+            const unsigned lane_y = (unsigned)((pr * p.ld_bny + piece * 8) * 2), lane_z = (unsigned)((pr * p.Cout + piece * 8) * 2);
+            float bm[8], bis[8], bga[8], bbe[8], bs1[8], bs2[8];
+            if constexpr (BNS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bm[j] = p.bn_mean[cb + piece * 8 + j]; bis[j] = p.bn_invstd[cb + piece * 8 + j];
+                    if constexpr (!FROMZ) { bga[j] = p.bn_gamma[cb + piece * 8 + j]; bbe[j] = p.bn_beta[cb + piece * 8 + j]; }
+                    bs1[j] = 0.f; bs2[j] = 0.f;
+                }
+            }
+            auto row_base = [&](const bf16_t* t, int ld, int a) {      // uniform: first pixel of output row a of this wave
+                const int oy = item_ty0 + rg * WT_R + a;
+                return reinterpret_cast<const unsigned char*>(t) + (((long long)(item_tile_img * p.H + oy) * p.W + item_tx0) * ld + cb) * 2;
+            };
+            // The BatchNorm tensors of a row are loaded while the row before it is worked on; where there is an addend as
+            // well it is loaded at the top of its own row (a third tensor a row ahead does not fit the register file).
+            constexpr bool ADD_AHEAD = ADD && !BNS;
+            bf16x8_t yv[2][4], zv[2][4], av[2][4];
+            auto load_row = [&](auto A_, auto AHEAD_) {
+                constexpr int a = A_, b = a & 1;
+                constexpr bool AHEAD = AHEAD_;
+                const int oy = item_ty0 + rg * WT_R + a;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (FULL || (oy < p.H && item_tx0 + pr + 8 * k < p.W)) {
+                        if constexpr (BNS && AHEAD) yv[b][k] = *reinterpret_cast<const bf16x8_t*>(row_base(p.bn_y, p.ld_bny, a) + (size_t)(8 * k * p.ld_bny * 2) + lane_y);
+                        if constexpr (FROMZ && AHEAD) zv[b][k] = *reinterpret_cast<const bf16x8_t*>(row_base(p.bn_z, p.Cout, a) + (size_t)(8 * k * p.Cout * 2) + lane_z);
+                        if constexpr (ADD && AHEAD == ADD_AHEAD) av[ADD_AHEAD ? b : 0][k] = *reinterpret_cast<const bf16x8_t*>(row_base(p.addend, p.ld_add, a) + (size_t)(8 * k * p.ld_add * 2) + lane_add);
+                    }
+                }
+            };
+            load_row(I0{}, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            wt_for<WT_R>([&](auto A_) {
+                constexpr int a = A_, b = a & 1;
+                const int oy = item_ty0 + rg * WT_R + a;
+                if constexpr (ADD && !ADD_AHEAD) { load_row(A_, std::false_type{}); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const f32x4_t v = acc[a][h][n];
+                        bf16x4_t o;
+                        o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+                        *reinterpret_cast<bf16x4_t*>(wr + h * 16 * WT_OUT_PITCH + n * 32) = o;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // (the barriers keep the compiler from issuing every row's loads at the top: 4 rows x 3 tensors of them do not fit)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (a + 1 < WT_R) load_row(std::integral_constant<int, a + 1>{}, std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned char* yrow = const_cast<unsigned char*>(row_base(p.y, p.ld_out, a));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (FULL || (oy < p.H && item_tx0 + pr + 8 * k < p.W)) {
+                        bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(rd + 8 * k * WT_OUT_PITCH);
+                        if constexpr (ADD) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)av[ADD_AHEAD ? b : 0][k][j]);
+                        }
+                        if constexpr (BNS) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float xh = ((float)yv[b][k][j] - bm[j]) * bis[j];
+                                float pre;
+                                if constexpr (FROMZ) pre = (float)zv[b][k][j]; else pre = xh * bga[j] + bbe[j];
+                                const float gv = pre > 0.f ? (float)v[j] : 0.f;
+                                bs1[j] += gv; bs2[j] += gv * xh;
+                            }
+                        }
+                        *reinterpret_cast<bf16x8_t*>(yrow + (size_t)(8 * k * p.ld_out * 2) + lane_out) = v;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (BNS) {
+                // lanes with equal lane & 7 hold the same 8 channels: fold lane bits 3 (row rotation), 4 and 5
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float u = bs1[j], q = bs2[j];
+                    u += wt_dpp<0x128>(u); q += wt_dpp<0x128>(q);
+                    u += __shfl_xor(u, 16, 64); q += __shfl_xor(q, 16, 64);
+                    u += __shfl_xor(u, 32, 64); q += __shfl_xor(q, 32, 64);
+                    if (pr == 0) *reinterpret_cast<float2*>(&red[wave][piece * 8 + j][0]) = float2{u, q};
+                }
+            }
+        };
+        if constexpr (EPI == 0) {
             if (want_stats) { if (full_tile) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
             else { if (full_tile) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}); }
+        } else {
+            if (full_tile) epilogue_x(std::true_type{}); else epilogue_x(std::false_type{});
         }
         __syncthreads();               // staging area and `red` complete; the next halo DMA may overwrite the buffer
-        if (want_stats && tid < WT_BN && !(p.dbg & 1)) {
+        if (want_stats && tid < WT_BN) {
             const int hh = tid >> 6, c = tid & 63;
             float2 o;
             o.x = red[hh * 4][c][0] + red[hh * 4 + 1][c][0] + red[hh * 4 + 2][c][0] + red[hh * 4 + 3][c][0];
@@ -410,40 +530,21 @@ __global__ __launch_bounds__(WT_THREADS, 1) void conv3x3_wide_kernel(WideParams 
         }
         // a tile inside the image issues exactly 16 row stores per wave (+ 1 for the statistics in waves 0 and 1): the next
         // two barriers admit them in flight; for an edge tile the count is not known and those barriers wait for them
-        stores_in_flight = (full_tile && !(p.dbg & 1)) ? 4 * WT_R + ((want_stats && wave < 2) ? 1 : 0) : 0;
+        stores_in_flight = full_tile ? 4 * WT_R + ((want_stats && wave < 2) ? 1 : 0) : 0;
         if (halo_deferred) { issue_halo(ph, (slice - 1) & 1); next_slice(ph); }
+        {   // first operands of the next item's first third (as at the end of every other third)
+            const unsigned bbn = b0 + (step % 3) * WT_THIRD_BYTES;
+            const unsigned hoffn = (slice & 1) * WT_HALO_BYTES;
+            const unsigned abn[2] = {a0[0][0] + hoffn, a0[0][1] + hoffn};
+            read_w(I0{}, bbn); read_row(I0{}, abn); read_w(I1{}, bbn); read_w(I2{}, bbn);
+        }
     }
 }
 
-// Fragment-order weight image: piece index ((((nb * chunks + chunk) * 3 + dx) * 3 + dy) * 2 + half) * 4 + n, then lane,
-// then 8 k-values.
+// Weight image (packed by ur_pack3x3_image, conv3x3_tile.hip): 16-byte piece index
+// ((((nb * chunks + chunk) * 3 + dx) * 3 + dy) * 2 + half) * 4 + n, then lane, then 8 k-values:
 //   forward : value = w[co = nb*128 + half*64 + n*16 + (lane & 15)][ci = chunk*32 + 8*(lane >> 4) + j][tap = dy*3 + dx]
 //   dgrad   : value = w[co = chunk*32 + 8*(lane >> 4) + j][ci = nb*128 + half*64 + n*16 + (lane & 15)][8 - (dy*3 + dx)]
-__global__ __launch_bounds__(256) void wide_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int cin, int cout,
-                                                        int dgrad, long long pieces) {
-    const int rows = dgrad ? cin : cout, redc = dgrad ? cout : cin;
-    const int chunks = redc / WT_KC;
-    for (long long pi = blockIdx.x * 256LL + threadIdx.x; pi < pieces; pi += (long long)gridDim.x * 256) {
-        const int lane = (int)(pi & 63);
-        long long f = pi >> 6;
-        const int n = (int)(f & 3); f >>= 2;
-        const int half = (int)(f & 1); f >>= 1;
-        const int dy = (int)(f % 3); f /= 3;
-        const int dx = (int)(f % 3); f /= 3;
-        const int chunk = (int)(f % chunks), nb = (int)(f / chunks);
-        const int r = nb * WT_BN + half * 64 + n * 16 + (lane & 15);
-        const int k0 = chunk * WT_KC + 8 * (lane >> 4);
-        const int tap = dy * 3 + dx;
-        bf16x8_t o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = 0.f;
-            if (r < rows) v = dgrad ? w[((size_t)(k0 + j) * cin + r) * 9 + (8 - tap)] : w[((size_t)r * cin + (k0 + j)) * 9 + tap];
-            o[j] = (bf16_t)v;
-        }
-        *reinterpret_cast<bf16x8_t*>(dst + pi * 8) = o;
-    }
-}
 
 int wide_check(const ur_conv_desc* d, bool dgrad) {
     UR_REQUIRE(d != nullptr, "conv3x3_wide: null descriptor");
@@ -459,21 +560,37 @@ int wide_check(const ur_conv_desc* d, bool dgrad) {
     return UR_OK;
 }
 
-int wide_launch(const void* src, const void* wpk, void* dst, float* stats, const ur_conv_desc* d, bool dgrad, hipStream_t st) {
+struct WideExtra {        // what the epilogues other than 0 read (see WideParams)
+    const void* addend; int ld_add;
+    const void* bn_y; int ld_bny; const void* bn_z; const float *mean, *invstd, *gamma, *beta;
+};
+
+int wide_launch(const void* src, const void* wpk, void* dst, float* stats, const ur_conv_desc* d, bool dgrad, hipStream_t st,
+                int epi = 0, const WideExtra* ex = nullptr) {
     WideParams p{};
     p.x = (const bf16_t*)src; p.wpk = (const bf16_t*)wpk; p.y = (bf16_t*)dst; p.stats = stats;
     p.N = d->n; p.H = d->h; p.W = d->w;
     p.Cin = dgrad ? d->cout : d->cin; p.Cout = dgrad ? d->cin : d->cout;
     p.ld_in = dgrad ? d->out_ld : d->in_ld; p.ld_out = dgrad ? d->in_ld : d->out_ld;
+    if (ex) {
+        p.addend = (const bf16_t*)ex->addend; p.ld_add = ex->ld_add ? ex->ld_add : p.Cout;
+        p.bn_y = (const bf16_t*)ex->bn_y; p.ld_bny = ex->ld_bny ? ex->ld_bny : p.Cout; p.bn_z = (const bf16_t*)ex->bn_z;
+        p.bn_mean = ex->mean; p.bn_invstd = ex->invstd; p.bn_gamma = ex->gamma; p.bn_beta = ex->beta;
+    }
     p.tiles_x = ur_cdiv(d->w, WT_TW); p.tiles_y = ur_cdiv(d->h, WT_TH);
     p.tiles = d->n * p.tiles_x * p.tiles_y;
     p.tiles8 = (p.tiles + 7) / 8 * 8;
     p.nblocks = p.Cout / WT_BN;
     p.items = p.tiles8 * p.nblocks;
-    if (const char* e = getenv("URESNET_WIDE_DBG")) p.dbg = atoi(e);
     int grid = 256;                                   // one workgroup per CU
     if (p.items < grid) grid = p.items;
-    hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(grid), dim3(WT_THREADS), 0, st, p);
+#define UR_WIDE_LAUNCH(E) hipLaunchKernelGGL(conv3x3_wide_kernel<E>, dim3(grid), dim3(WT_THREADS), 0, st, p)
+    switch (epi) {           // (4, 5 and 6 compile but leave no registers for the main loop: those stay with the tile kernel)
+        case 0: UR_WIDE_LAUNCH(0); break;
+        case 1: UR_WIDE_LAUNCH(1); break;
+        default: UR_WIDE_LAUNCH(3); break;
+    }
+#undef UR_WIDE_LAUNCH
     return ur_check_launch("conv3x3_wide");
 }
 
@@ -495,10 +612,17 @@ size_t ur_conv3x3_wide_packed_elems(const ur_conv_desc* d) { return d ? (size_t)
 int ur_conv3x3_wide_pack_weight(const float* w, void* packed, const ur_conv_desc* d, int dgrad, ur_stream_t s) {
     if (int e = wide_check(d, dgrad != 0)) return e;
     UR_REQUIRE(w && packed, "conv3x3_wide_pack_weight: null pointer");
-    const long long pieces = (long long)d->cin * d->cout * 9 / 8;
-    hipLaunchKernelGGL(wide_pack_kernel, dim3(ur_grid_1d(pieces, 256, 4096)), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed,
-                       d->cin, d->cout, dgrad != 0, pieces);
-    return ur_check_launch("conv3x3_wide_pack_weight");
+    return ur_pack3x3_image(w, packed, d->cin, d->cout, dgrad != 0, 1, (hipStream_t)s);
+}
+
+// Whether this kernel is the faster one for the layer (measured against ur_conv3x3_tile_* on MI355X): it needs enough
+// (tile, channel block) items to occupy the 256 CUs without a ragged last round -- 384 items are two rounds of which
+// the second is half empty, and there the smaller workgroups of the tile kernel balance better.
+int ur_conv3x3_wide_preferred(const ur_conv_desc* d, int dgrad) {
+    if (!ur_conv3x3_wide_supported(d, dgrad)) return 0;
+    const long long tiles = (long long)d->n * ur_cdiv(d->h, WT_TH) * ur_cdiv(d->w, WT_TW);
+    const long long items = tiles * ((dgrad ? d->cin : d->cout) / WT_BN);
+    return (items >= 128 && items <= 256) || items >= 512;
 }
 
 int ur_conv3x3_wide_stats_rows(const ur_conv_desc* d) { return d ? d->n * ur_cdiv(d->h, WT_TH) * ur_cdiv(d->w, WT_TW) : 0; }
@@ -517,6 +641,32 @@ int ur_conv3x3_wide_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, 
     UR_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)w_packed_dgrad % 16) == 0,
                "conv3x3_wide_dgrad: tensors must be 16-byte aligned");
     return wide_launch(dy, w_packed_dgrad, dx, nullptr, d, true, (hipStream_t)s);
+}
+
+int ur_conv3x3_wide_dgrad_add(const void* dy, const void* w_packed_dgrad, void* dx, const void* addend, int add_ld,
+                              const ur_conv_desc* d, ur_stream_t s) {
+    if (int e = wide_check(d, true)) return e;
+    UR_REQUIRE(dy && w_packed_dgrad && dx && addend, "conv3x3_wide_dgrad_add: null pointer");
+    UR_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)w_packed_dgrad % 16) == 0 &&
+                   ((uintptr_t)addend % 16) == 0 && add_ld % 8 == 0,
+               "conv3x3_wide_dgrad_add: tensors must be 16-byte aligned, the addend's pitch a multiple of 8");
+    WideExtra ex{};
+    ex.addend = addend; ex.ld_add = add_ld;
+    return wide_launch(dy, w_packed_dgrad, dx, nullptr, d, true, (hipStream_t)s, 1, &ex);
+}
+
+int ur_conv3x3_wide_dgrad_bnsums(const void* dy, const void* w_packed_dgrad, void* dx, const void* bn_y, int bn_y_ld,
+                                 const float* mean, const float* invstd, const float* gamma, const float* beta, float* partial,
+                                 const ur_conv_desc* d, ur_stream_t s) {
+    if (int e = wide_check(d, true)) return e;
+    UR_REQUIRE(dy && w_packed_dgrad && dx && bn_y && mean && invstd && gamma && beta && partial,
+               "conv3x3_wide_dgrad_bnsums: null pointer");
+    UR_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)w_packed_dgrad % 16) == 0 &&
+                   ((uintptr_t)bn_y % 16) == 0 && bn_y_ld % 8 == 0,
+               "conv3x3_wide_dgrad_bnsums: tensors must be 16-byte aligned, pitches multiples of 8");
+    WideExtra ex{};
+    ex.bn_y = bn_y; ex.ld_bny = bn_y_ld; ex.mean = mean; ex.invstd = invstd; ex.gamma = gamma; ex.beta = beta;
+    return wide_launch(dy, w_packed_dgrad, dx, partial, d, true, (hipStream_t)s, 3, &ex);
 }
 
 }  // extern "C"

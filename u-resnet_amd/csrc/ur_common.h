@@ -17,6 +17,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // ---- host-side error plumbing (never throws across the C ABI) -----------------------------
 void ur_set_error(const char* fmt, ...);
 int ur_check_launch(const char* what);
+// fragment-order image of a 3x3 layer's weights for the tile kernel (wide = 0) or the 128-channel kernel (wide = 1)
+int ur_pack3x3_image(const float* w, void* packed, int cin, int cout, int dgrad, int wide, hipStream_t s);
 
 #define UR_REQUIRE(cond, ...)                 \
     do {                                      \

@@ -7,6 +7,7 @@ kernels.  Parameters and their gradients are fp32 in PyTorch's native layouts, s
 state_dicts are interchangeable with the reference's.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -211,8 +212,8 @@ def _repack_stale_tile_images(device):
         new_key = (w.data_ptr(), w._version, _weights_epoch) + key[3:]
         if key == new_key or key[0] != new_key[0]:
             continue
-        dg = int(mode == "tile_dgrad")
-        rows.append((w.data_ptr(), packed.data_ptr(), key[4], key[5], dg, nblocks))
+        dg = int(mode.endswith("dgrad"))
+        rows.append((w.data_ptr(), packed.data_ptr(), key[4], key[5], dg | (2 if mode.startswith("wide") else 0), nblocks))
         nblocks += query("ur_conv3x3_tile_pack_blocks", key[4], key[5], dg)
         hits.append((pw, mode, new_key, packed))
     _tile_images[:] = live
@@ -234,9 +235,10 @@ class PackedWeights:
     def __init__(self):
         self._cache = {}
 
-    def get_tile(self, weight, d, dgrad):
-        """Fragment-order image for the LDS-tiled 3x3 kernel."""
-        mode = "tile_dgrad" if dgrad else "tile_fwd"
+    def get_tile(self, weight, d, dgrad, wide=False):
+        """Fragment-order image for the LDS-tiled 3x3 kernel (wide: in the piece order of the 128-channel kernel)."""
+        mode = ("wide_" if wide else "tile_") + ("dgrad" if dgrad else "fwd")
+        kern = "wide" if wide else "tile"
         key = (weight.data_ptr(), weight._version, _weights_epoch, d.dtype, d.cin, d.cout)
         hit = self._cache.get(mode)
         if hit is not None and hit[0] == key:
@@ -246,8 +248,8 @@ class PackedWeights:
             hit = self._cache.get(mode)
             if hit[0] == key:
                 return hit[1]
-        packed = torch.empty(query("ur_conv3x3_tile_packed_elems", C.byref(d)), dtype=torch.bfloat16, device=weight.device)
-        call("ur_conv3x3_tile_pack_weight", weight.data_ptr(), packed.data_ptr(), C.byref(d), int(dgrad), _stream())
+        packed = torch.empty(query("ur_conv3x3_%s_packed_elems" % kern, C.byref(d)), dtype=torch.bfloat16, device=weight.device)
+        call("ur_conv3x3_%s_pack_weight" % kern, weight.data_ptr(), packed.data_ptr(), C.byref(d), int(dgrad), _stream())
         if hit is None:
             _tile_images.append((weakref.ref(self), mode, weakref.ref(weight)))
         self._cache[mode] = (key, packed)
@@ -278,6 +280,7 @@ class PackedWeights:
 kernel_timings = None
 kernel_timing_tags = None       # optional set of tags: only those launches are bracketed (each event costs about a microsecond)
 use_tile_kernel = True          # False forces the generic implicit-GEMM kernel (A/B comparisons, tests)
+use_wide_kernel = os.environ.get("URESNET_WIDE", "1") != "0"   # False: the 128-channel 3x3 kernel is never chosen (A/B comparisons)
 use_pw_kernel = True            # False: 1x1 convolutions go through the generic kernel too
 
 
@@ -386,12 +389,13 @@ class _Conv2d(Function):
         y = out[0] if (win_ld and (not tile or tile_direct)) else empty_nhwc(d.n, cout, d.oh, d.ow, x.dtype, x.device)
         stats = None
         if tile:
-            wp = packs.get_tile(weight, d, False)
+            kern = "wide" if use_wide_kernel and query("ur_conv3x3_wide_preferred", C.byref(d), 0) else "tile"
+            wp = packs.get_tile(weight, d, False, kern == "wide")
             if want_stats:
-                rows = query("ur_conv3x3_tile_stats_rows", C.byref(d))
+                rows = query("ur_conv3x3_%s_stats_rows" % kern, C.byref(d))
                 stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
             with _Timed("tile_fwd", _conv_flops(d), d):
-                call("ur_conv3x3_tile_fwd", x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(stats), C.byref(d), _stream())
+                call("ur_conv3x3_%s_fwd" % kern, x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(stats), C.byref(d), _stream())
         else:
             if cin % 8:
                 x = _pad_channels(x, _pad8(cin))
@@ -456,7 +460,6 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             dx = empty_nhwc(d.n, d.cin, d.h, d.w, x.dtype, x.device)
             if tile_d:
-                wp = ctx.packs.get_tile(weight, d, True)
                 add_ld = 0
                 if dalias is not None and dalias.dtype == x.dtype and dalias.data_ptr() % 16 == 0:
                     add_ld = _channel_pitch(dalias)
@@ -465,8 +468,25 @@ class _Conv2d(Function):
                 fuse = (fuse_bn_bwd_sums and rec is not None and (dalias is None or add_ok)
                         and tuple(rec.y.shape) == tuple(dx.shape) and rec.y.dtype == dx.dtype and _is_nhwc_dense(rec.y)
                         and (not rec.use_z or (_is_nhwc_dense(x) and x.data_ptr() % 16 == 0)))
+                # the 128-channel kernel has the plain, the addend and the mask-from-y BatchNorm epilogues
+                wide = (use_wide_kernel and not (fuse and (rec.use_z or dalias is not None))
+                        and bool(query("ur_conv3x3_wide_preferred", C.byref(d), 1)))
+                wp = ctx.packs.get_tile(weight, d, True, wide)
                 with _Timed("tile_dgrad_bn" if fuse else "tile_dgrad", _conv_flops(d), d):
-                    if fuse:
+                    if wide and fuse:
+                        rows = query("ur_conv3x3_wide_stats_rows", C.byref(d))
+                        partial = torch.empty((rows, d.cin, 2), dtype=torch.float32, device=x.device)
+                        call("ur_conv3x3_wide_dgrad_bnsums", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), rec.y.data_ptr(), d.cin,
+                             rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.gamma.data_ptr(), rec.beta.data_ptr(),
+                             partial.data_ptr(), C.byref(d), _stream())
+                        rec.partial, rec.dz_ptr, rec.dz_version = partial, dx.data_ptr(), dx._version
+                    elif wide and add_ok:
+                        call("ur_conv3x3_wide_dgrad_add", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), dalias.data_ptr(), add_ld,
+                             C.byref(d), _stream())
+                        dalias = None
+                    elif wide:
+                        call("ur_conv3x3_wide_dgrad", dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), C.byref(d), _stream())
+                    elif fuse:
                         # dx is the gradient of a BatchNorm+ReLU output: its backward sums come out of this kernel's epilogue
                         rows = query("ur_conv3x3_tile_dgrad_stats_rows", C.byref(d))
                         partial = torch.empty((rows, d.cin, 2), dtype=torch.float32, device=x.device)
