@@ -265,7 +265,7 @@ def main():
     def timed_steps(fn, with_events):
         if with_events and not args.no_kernel_timing:
             ops.kernel_timings = []
-            ops.kernel_timing_tags = None if args.all_kernel_timing else {"tile_fwd", "tile_dgrad", "tile_dgrad_bn"}
+            ops.kernel_timing_tags = None if args.all_kernel_timing else {"tile_fwd", "tile_dgrad", "tile_dgrad_bn", "wide_fwd", "wide_dgrad", "wide_dgrad_bn", "tile_wgrad"}
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss, _ = fn()
@@ -304,8 +304,11 @@ def main():
                 "conv3x3_tile_kernel<R, 0|1> (3x3 s1 p1 forward + plain backward-data launches)": ("tile_fwd", "tile_dgrad"),
                 "conv3x3_tile_kernel<R, 3..6> (backward-data launches that also read a BatchNorm's input and emit its "
                 "backward sums: the work of a separate HBM pass inside this kernel)": ("tile_dgrad_bn",),
+                "conv3x3_wide_kernel<0|1> (3x3 s1 p1 layers producing >= 128 channels: forward + plain backward-data launches)":
+                    ("wide_fwd", "wide_dgrad"),
+                "conv3x3_wide_kernel<3> (the same with the BatchNorm-backward sums in the epilogue)": ("wide_dgrad_bn",),
                 "conv_igemm_kernel (generic implicit GEMM: stem, 1x1, ConvT, skinny layers)": ("igemm_fwd", "igemm_dgrad", "pw_fwd", "pw_dgrad"),
-                "wgrad3x3_tile_kernel (3x3 s1 p1 backward-weight + slab reduce)": ("tile_wgrad",),
+                "wgrad3x3_strip_kernel (3x3 s1 p1 backward-weight; the timed launches include its slab reduction)": ("tile_wgrad",),
                 "conv_wgrad_kernel (generic backward-weight + slab reduce)": ("wgrad",),
             }
             summary = {}
@@ -321,9 +324,12 @@ def main():
             dom = summary.pop(dominant)
             traffic = source = None
             default_workload = (B, H, W, args.dtype, world) == (6, 512, 1024, "bf16", 1)
-            if default_workload and dominant.startswith("conv3x3_tile_kernel"):
-                traffic, source = pmc_traffic("conv3x3_tile_kernel (BatchNorm-backward sums in the epilogue)"
-                                              if "3..6" in dominant else "conv3x3_tile_kernel")
+            if default_workload and dominant.startswith("conv3x3_"):
+                base = dominant.split("<")[0]
+                traffic, source = pmc_traffic(base + (" (BatchNorm-backward sums in the epilogue)"
+                                                      if ("3..6" in dominant or "<3>" in dominant) else ""))
+            elif default_workload and dominant.startswith("wgrad3x3_"):
+                traffic, source = pmc_traffic("wgrad3x3_strip_kernel")
             # operands of the dominant group's launches: activations in and out once, the weight image once
             esz = 2 if dtype == torch.bfloat16 else 4
             dom_bytes = [(n_ * h_ * w_ * (ci + co) + ci * co * k_ * k_) * esz

@@ -19,6 +19,9 @@ def short(name):
     m = re.search(r"conv3x3_tile_kernel<\d+, (\d+)>", name)
     if m:
         return "conv3x3_tile_kernel" if int(m.group(1)) <= 2 else "conv3x3_tile_kernel (BatchNorm-backward sums in the epilogue)"
+    m = re.search(r"conv3x3_wide_kernel<(\d+)>", name)
+    if m:
+        return "conv3x3_wide_kernel" if int(m.group(1)) <= 2 else "conv3x3_wide_kernel (BatchNorm-backward sums in the epilogue)"
     m = re.search(r"(\w+_kernel)", name)
     return m.group(1) if m else name[:40]
 

@@ -394,7 +394,7 @@ class _Conv2d(Function):
             if want_stats:
                 rows = query("ur_conv3x3_%s_stats_rows" % kern, C.byref(d))
                 stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
-            with _Timed("tile_fwd", _conv_flops(d), d):
+            with _Timed(kern + "_fwd", _conv_flops(d), d):
                 call("ur_conv3x3_%s_fwd" % kern, x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(stats), C.byref(d), _stream())
         else:
             if cin % 8:
@@ -472,7 +472,7 @@ class _Conv2d(Function):
                 wide = (use_wide_kernel and not (fuse and (rec.use_z or dalias is not None))
                         and bool(query("ur_conv3x3_wide_preferred", C.byref(d), 1)))
                 wp = ctx.packs.get_tile(weight, d, True, wide)
-                with _Timed("tile_dgrad_bn" if fuse else "tile_dgrad", _conv_flops(d), d):
+                with _Timed(("wide" if wide else "tile") + ("_dgrad_bn" if fuse else "_dgrad"), _conv_flops(d), d):
                     if wide and fuse:
                         rows = query("ur_conv3x3_wide_stats_rows", C.byref(d))
                         partial = torch.empty((rows, d.cin, 2), dtype=torch.float32, device=x.device)
