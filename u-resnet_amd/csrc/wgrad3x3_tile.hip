@@ -209,8 +209,13 @@ __device__ __forceinline__ int swz16(int pix, int c) {
     return pix * 128 + ((((c >> 4) ^ ((pix >> 1) & 1) ^ (((pix >> 3) & 1) << 1)) & 3) << 5) + (c & 15) * 2;
 }
 
-template <bool M16>
+// SHIFT (with M16): the x fragments of the three horizontal taps are the same pixels shifted by 0, 1 and 2, and a lane's
+// fragment is 8 CONSECUTIVE pixels of one channel: one 12-pixel read (three transposing reads instead of six) serves all
+// three taps -- registers 0..3, registers 1..4, and four v_alignbit in between.  Backward-weight has the fewest MFMAs per LDS
+// read of the three convolution kernels; this takes 43 % of its reads away.
+template <bool M16, bool SHIFT = false>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_strip_kernel(WgTileParams p) {
+    static_assert(M16 || !SHIFT, "the shifted-fragment form is written for the 16x16x32 operand layout");
     constexpr int TH = 2;
     constexpr int HP = M16 ? HPITCH2 : HPITCH;
     constexpr int DY_PIX = TH * TW, DY_BYTES = DY_PIX * 128, HALO_BYTES = 4 * HP * 128;
@@ -298,15 +303,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_strip_kernel(WgTileParam
     const int lch = M16 ? 4 * (li & 3) : 16 * (g & 1) + 4 * (li & 3);
     constexpr int NH = M16 ? 2 : 1;                      // 16-channel halves of the wave's 32 co / 32 ci
     const unsigned dyl0 = (unsigned)(size_t)dyl, xl0 = (unsigned)(size_t)xl;
-    unsigned a_base[NH][2], b_base[3][NH][2];
+    unsigned a_base[NH][2], b_base[SHIFT ? 1 : 3][NH][SHIFT ? 3 : 2];
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            a_base[h][s] = dyl0 + sw(lpix + 4 * s, wa * 32 + 16 * h + lch);
+        for (int s = 0; s < 2; ++s) a_base[h][s] = dyl0 + sw(lpix + 4 * s, wa * 32 + 16 * h + lch);
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) b_base[dx][h][s] = xl0 + sw(lpix + 4 * s + dx, wb * 32 + 16 * h + lch);
-        }
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int s = 0; s < (SHIFT ? 3 : 2); ++s)
+#pragma unroll
+            for (int dx = 0; dx < (SHIFT ? 1 : 3); ++dx) b_base[dx][h][s] = xl0 + sw(lpix + 4 * s + dx, wb * 32 + 16 * h + lch);
 
     // Ring rotation without a second copy of the loop: halo row hr sits in slot (hr + 2k) & 3, i.e. two rows further on for
     // hr < 2 and two rows back for hr >= 2 when k = 1.  The two byte offsets are added to the lane bases per tile.
@@ -321,10 +328,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_strip_kernel(WgTileParam
             sfor<4>([&](auto HR_) {
                 constexpr int hr = HR_;
                 bf16x8_t bf[3][2];
-                sfor<3>([&](auto DX_) { sfor<2>([&](auto H_) {
-                    constexpr int dx = DX_, h = H_;
-                    bf[dx][h] = tr_frag_u(b_base[dx][h][0] + rot[hr >> 1], b_base[dx][h][1] + rot[hr >> 1], (hr * HP) * 128);
-                }); });
+                if constexpr (SHIFT) {
+                    sfor<2>([&](auto H_) {
+                        constexpr int h = H_;
+                        unsigned w[6];                       // pixels 8g .. 8g+11 of this lane's channel, two per register
+                        sfor<3>([&](auto S_) {
+                            constexpr int sx = S_;
+                            const s16x4_t q = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (lds_s16x4_ptr)(size_t)(b_base[0][h][sx] + rot[hr >> 1] + (hr * HP) * 128));
+                            const uint2 u = __builtin_bit_cast(uint2, q);
+                            w[2 * sx] = u.x; w[2 * sx + 1] = u.y;
+                        });
+                        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                        bf[0][h] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[0], w[1], w[2], w[3]});
+                        bf[1][h] = __builtin_bit_cast(bf16x8_t, (u32x4_t){__builtin_amdgcn_alignbit(w[1], w[0], 16),
+                                                                          __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                                                                          __builtin_amdgcn_alignbit(w[3], w[2], 16),
+                                                                          __builtin_amdgcn_alignbit(w[4], w[3], 16)});
+                        bf[2][h] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[1], w[2], w[3], w[4]});
+                    });
+                } else {
+                    sfor<3>([&](auto DX_) { sfor<2>([&](auto H_) {
+                        constexpr int dx = DX_, h = H_;
+                        bf[dx][h] = tr_frag_u(b_base[dx][h][0] + rot[hr >> 1], b_base[dx][h][1] + rot[hr >> 1], (hr * HP) * 128);
+                    }); });
+                }
                 sfor<TH>([&](auto R_) {
                     constexpr int r = R_, dy = hr - r;
                     if constexpr (dy >= 0 && dy <= 2) {
@@ -478,12 +506,13 @@ int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, 
     p.ci_blocks = d->cin / BI;
     p.pairs = pl.pairs; p.nsplit = pl.nsplit;
     p.xcd_order = pl.nsplit % 8 == 0;
-    // 3 (default): column strips with a rolling halo on the 16x16x32 MFMA; 2: the same on 32x32x16; 1: the first kernel
-    // (every tile stages its whole halo).  Measured on 6 x 256 x 512, 128 -> 128: 231 / 238 / 243 us.
-    static const int version = [] { const char* e = getenv("URESNET_WGRAD_V"); return e ? atoi(e) : 3; }();
-    if (version == 2 || version == 3) {
+    // 4 (default): column strips with a rolling halo on the 16x16x32 MFMA, one x fragment read per three horizontal taps;
+    // 3: a read per tap; 2: strips on 32x32x16; 1: the first kernel (every tile stages its whole halo).
+    static const int version = [] { const char* e = getenv("URESNET_WGRAD_V"); return e ? atoi(e) : 4; }();
+    if (version >= 2 && version <= 4) {
         p.tiles_y = ur_cdiv(d->h, 2); p.tiles = d->n * p.tiles_x * p.tiles_y;
-        if (version == 3) hipLaunchKernelGGL((wgrad3x3_strip_kernel<true>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
+        if (version == 4) hipLaunchKernelGGL((wgrad3x3_strip_kernel<true, true>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
+        else if (version == 3) hipLaunchKernelGGL((wgrad3x3_strip_kernel<true>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
         else hipLaunchKernelGGL((wgrad3x3_strip_kernel<false>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
     } else
     if (tile_rows() == 4) hipLaunchKernelGGL((wgrad3x3_tile_kernel<4, 1>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
