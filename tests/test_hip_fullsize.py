@@ -104,6 +104,31 @@ def test_config3_tiled_and_generic_kernels_agree_at_full_size(pkg):
     assert rel_l2(res[True][3], res[False][3]) < 0.3
 
 
+def test_config3_step_is_bit_reproducible_run_to_run(pkg):
+    """Split reductions (backward-weight slabs, BatchNorm partial rows, loss partials) are summed in a fixed order and no
+    kernel on the path uses floating-point atomics: two training steps from the same state on the same 2 x 512 x 1024
+    batch give bit-identical logits, loss, gradients and updated weights -- with the tile and the 128-channel kernels
+    both in play (the second image pair makes the 128- and 256-channel levels large enough for the latter)."""
+    x, y = _seg_inputs(512, 1024, b=2)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        m = pkg.modules.U_ResNet.UResNetNewEUCB(19, 3, 64).set_compute_dtype(torch.bfloat16).to(DEV).train()
+        opt = pkg.train.Adam(m.parameters(), lr=1e-4)
+        pkg.ops.kernel_timings = []
+        try:
+            loss, out = pkg.train.seg_train_step(m, opt, x.to(DEV), y.to(DEV))
+        finally:
+            tags, pkg.ops.kernel_timings = set(t[0] for t in pkg.ops.kernel_timings), None
+        assert {"tile_fwd", "wide_fwd", "tile_dgrad_bn", "wide_dgrad_bn", "tile_wgrad"} <= tags
+        runs.append((out.detach().clone(), loss.detach().clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None],
+                     [p.detach().clone() for p in m.parameters()]))
+    a, b = runs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert len(a[2]) == len(b[2]) and all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+    assert all(torch.equal(u, v) for u, v in zip(a[3], b[3]))
+
+
 def test_config2_mini_imagenet_step_matches_oracle(pkg, oracle):
     torch.manual_seed(0)
     ref = oracle.MiniU_ResNet(100, 3).train()
