@@ -349,14 +349,19 @@ def main():
                     "timing_region": ("the timed steps" if graphed is None else
                                       "the same %d steps run eagerly right after the timed graph replays (%.3f ms per step)"
                                       % (args.steps, eager_elapsed / args.steps * 1e3))}
-            # the 3x3 forward / backward-data launches as one family (two kernels, each with epilogue variants): the number
+            # the 3x3 forward / backward-data launches as one family (two kernels, each with epilogue variants): the numbers
             # comparable with runs that had a single kernel for all of them
-            fam = [kernels[t] for t in ("tile_fwd", "tile_dgrad", "tile_dgrad_bn", "wide_fwd", "wide_dgrad", "wide_dgrad_bn") if t in kernels]
-            if fam:
+            def family(tags):
+                fam = [kernels[t] for t in tags if t in kernels]
+                if not fam:
+                    return None
                 fl, sec, n = sum(k[1] for k in fam), sum(k[2] for k in fam), sum(k[0] for k in fam)
-                roof["conv3x3_forward_and_backward_data_all_kernels"] = {
-                    "achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4), "launches": n,
-                    "avg_launch_ms": round(sec / n * 1e3, 4), "time_share_of_step": round(sec / elapsed, 3)}
+                return {"achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4), "launches": n,
+                        "avg_launch_ms": round(sec / n * 1e3, 4), "time_share_of_step": round(sec / elapsed, 3)}
+            roof["conv3x3_forward_and_backward_data"] = {
+                "plain_launches": family(("tile_fwd", "tile_dgrad", "wide_fwd", "wide_dgrad")),
+                "launches_that_also_emit_batchnorm_backward_sums": family(("tile_dgrad_bn", "wide_dgrad_bn")),
+                "all": family(("tile_fwd", "tile_dgrad", "tile_dgrad_bn", "wide_fwd", "wide_dgrad", "wide_dgrad_bn"))}
             for tag, (n, by, sec) in kernels.items():
                 if tag.startswith("hbm:") and n:
                     summary[tag[4:] + " (HBM-bound, algorithmic bytes)"] = {

@@ -268,6 +268,12 @@ int ur_channel_shuffle(const void* x, void* y, int dtype, long long rows, int c,
 int ur_act_fwd(const void* x, void* y, int dtype, long long count, int act, float slope, ur_stream_t s);
 int ur_act_bwd(const void* dy, const void* x, void* dx, int dtype, long long count, int act, float slope,
                ur_stream_t s);
+/* nn.PReLU(num_parameters = nslope, init) of act_layer('prelu') (S/C:26-27): y = x > 0 ? x : slope[c] * x, channels
+ * fastest (count = rows * c), nslope = 1 or c.  Backward writes dx and slope_terms[count] = dy * x * [x <= 0] (fp32); the
+ * slope gradient is their per-channel column sum (ur_colsum; over everything when nslope == 1). */
+int ur_prelu_fwd(const void* x, const float* slope, int nslope, void* y, int dtype, long long count, int c, ur_stream_t s);
+int ur_prelu_bwd(const void* dy, const void* x, const float* slope, int nslope, void* dx, float* slope_terms, int dtype,
+                 long long count, int c, ur_stream_t s);
 /* a += b (gradient accumulation at forks), elementwise over `count` elements */
 int ur_add_inplace(void* a, const void* b, int dtype, long long count, ur_stream_t s);
 /* layout / dtype conversion at the model boundary */

@@ -578,7 +578,7 @@ def test_classification_variant_fp32_matches_reference(pkg, name, mod, cls, args
 
 @pytest.mark.parametrize("act", ["relu", "relu6", "leakyrelu", "gelu", "hswish"])
 def test_act_layer_variants_match_torch(pkg, act):
-    """act_layer (S/C:17-34): every activation the factory hands out except prelu, forward and backward against the
+    """act_layer (S/C:17-34): the parameter-free activations the factory hands out, forward and backward against the
     torch.nn layer the reference would construct, fp32 1e-5 and bf16 1e-2 (inputs rounded to bf16 first); kinks at 0,
     +-3 and 6 are hit exactly."""
     ref_layer = {"relu": torch.nn.ReLU(), "relu6": torch.nn.ReLU6(), "leakyrelu": torch.nn.LeakyReLU(0.2),
@@ -599,9 +599,41 @@ def test_act_layer_variants_match_torch(pkg, act):
         assert rel_l2(host(pkg, yd), yr.detach()) < tol, (act, dtype)
         assert rel_l2(host(pkg, xd.grad), xr.grad) < tol, (act, dtype)
     with pytest.raises(NotImplementedError):
-        pkg.modules._blocks.act_layer("prelu")
-    with pytest.raises(NotImplementedError):
         pkg.modules._blocks.act_layer("swish")
+
+
+@pytest.mark.parametrize("n_prelu", [1, 16])
+def test_act_layer_prelu_matches_torch(pkg, n_prelu):
+    """act_layer('prelu', neg_slope, n_prelu) = nn.PReLU(num_parameters=n_prelu, init=neg_slope) (S/C:26-27): same parameter
+    name / shape / initial value, output, input gradient and slope gradient (a sum over every element with x <= 0) against
+    torch; fp32 1e-5, bf16 1e-2.  A channel count that does not match the parameter raises torch's message."""
+    layer = pkg.modules._blocks.act_layer("prelu", neg_slope=0.3, n_prelu=n_prelu)
+    ref_layer = torch.nn.PReLU(num_parameters=n_prelu, init=0.3)
+    assert type(layer).__name__ == "PReLU" and list(layer.state_dict()) == list(ref_layer.state_dict())
+    assert torch.equal(layer.weight.detach().cpu(), ref_layer.weight.detach())
+    g = torch.Generator().manual_seed(18)
+    w0 = torch.rand(n_prelu, generator=g) * 0.5
+    x = torch.randn(2, 16, 9, 13, generator=g) * 2
+    x[0, 0, 0, :2] = torch.tensor([0.0, -0.0])
+    go = torch.randn(2, 16, 9, 13, generator=g)
+    layer.to(DEV)
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        with torch.no_grad():
+            ref_layer.weight.copy_(w0); layer.weight.copy_(w0.to(DEV))
+        ref_layer.weight.grad = None; layer.weight.grad = None
+        xr = x.detach().to(dtype).float().clone().requires_grad_(True)
+        yr = ref_layer(xr)
+        yr.backward(go.to(dtype).float())
+        xd = pkg.ops.as_activation(x.to(DEV), dtype).detach().requires_grad_(True)
+        yd = layer(xd)
+        yd.backward(pkg.ops.as_activation(go.to(DEV), dtype))
+        assert rel_l2(host(pkg, yd), yr.detach()) < tol, dtype
+        assert rel_l2(host(pkg, xd.grad), xr.grad) < tol, dtype
+        assert layer.weight.grad.shape == ref_layer.weight.grad.shape
+        assert rel_l2(layer.weight.grad.cpu(), ref_layer.weight.grad) < tol, dtype
+    if n_prelu > 1:
+        with pytest.raises(RuntimeError, match="Mismatch of parameter numbers and input channel size"):
+            layer(pkg.ops.as_activation(torch.randn(1, 8, 4, 4).to(DEV), torch.float32))
 
 
 def test_shape_broken_cifar_classes_raise_the_reference_error(pkg):

@@ -433,6 +433,27 @@ __global__ __launch_bounds__(NT) void act_bwd_kernel(const T* __restrict__ dy, c
     GRID_STRIDE(i, count) dx[i] = ur_from_float<T>(ur_to_float(dy[i]) * act_grad(ur_to_float(x[i]), act, slope));
 }
 
+// PReLU (nn.PReLU(num_parameters = nw, init), S/C:26-27): y = x > 0 ? x : a[c] * x with a learnable slope per channel
+// (nw == C) or one for all (nw == 1); channels are the fastest dimension (NHWC, or [rows][C]).  Backward writes dx and the
+// per-element slope-gradient terms t = dy * x * [x <= 0] in fp32; their column sums (ur_colsum) are the slope's gradient.
+template <typename T>
+__global__ __launch_bounds__(NT) void prelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ a, int nw, T* __restrict__ y,
+                                                       long long count, int C) {
+    GRID_STRIDE(i, count) {
+        const float v = ur_to_float(x[i]);
+        y[i] = ur_from_float<T>(v > 0.f ? v : a[nw == 1 ? 0 : (int)(i % C)] * v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void prelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ a,
+                                                       int nw, T* __restrict__ dx, float* __restrict__ t, long long count, int C) {
+    GRID_STRIDE(i, count) {
+        const float v = ur_to_float(x[i]), g = ur_to_float(dy[i]);
+        dx[i] = ur_from_float<T>(v > 0.f ? g : a[nw == 1 ? 0 : (int)(i % C)] * g);
+        t[i] = v > 0.f ? 0.f : g * v;
+    }
+}
+
 // ------------------------------------------------------------------ [B][R][S] -> [B][S][R] with dtype conversion
 template <typename TS, typename TD>
 __global__ void transpose_cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int R, int S) {
@@ -702,6 +723,24 @@ int ur_act_bwd(const void* dy, const void* x, void* dx, int dtype, long long cou
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(ur_grid_1d(count, NT)), dim3(NT), 0,
                                                 (hipStream_t)s, (const T*)dy, (const T*)x, (T*)dx, count, act, slope));
     return ur_check_launch("act_bwd");
+}
+
+int ur_prelu_fwd(const void* x, const float* slope, int nslope, void* y, int dtype, long long count, int c, ur_stream_t s) {
+    UR_REQUIRE(x && slope && y && count > 0 && c > 0 && count % c == 0 && (nslope == 1 || nslope == c), "prelu_fwd: bad arguments");
+    UR_REQUIRE_32BIT(count, "prelu_fwd");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((prelu_fwd_kernel<T>), dim3(ur_grid_1d(count, NT)), dim3(NT), 0, (hipStream_t)s,
+                                                (const T*)x, slope, nslope, (T*)y, count, c));
+    return ur_check_launch("prelu_fwd");
+}
+
+int ur_prelu_bwd(const void* dy, const void* x, const float* slope, int nslope, void* dx, float* slope_terms, int dtype,
+                 long long count, int c, ur_stream_t s) {
+    UR_REQUIRE(dy && x && slope && dx && slope_terms && count > 0 && c > 0 && count % c == 0 && (nslope == 1 || nslope == c),
+               "prelu_bwd: bad arguments");
+    UR_REQUIRE_32BIT(count, "prelu_bwd");
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((prelu_bwd_kernel<T>), dim3(ur_grid_1d(count, NT)), dim3(NT), 0, (hipStream_t)s,
+                                                (const T*)dy, (const T*)x, slope, nslope, (T*)dx, slope_terms, count, c));
+    return ur_check_launch("prelu_bwd");
 }
 
 int ur_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int h, int w, ur_stream_t s) {

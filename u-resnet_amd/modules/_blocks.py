@@ -34,7 +34,7 @@ def act_layer(act, inplace=False, neg_slope=0.2, n_prelu=1):
     if act == 'hswish':
         return hnn.Hardswish(inplace)
     if act == 'prelu':
-        raise NotImplementedError("activation layer [prelu] has no HIP kernel (U-ResNet never selects it)")
+        return hnn.PReLU(num_parameters=n_prelu, init=neg_slope)
     raise NotImplementedError('activation layer [%s] is not found' % act)
 
 

@@ -122,6 +122,13 @@ class GELU(tnn.GELU):
         return ops.activation(x, _lib.ACT_GELU)
 
 
+class PReLU(tnn.PReLU):
+    """Learnable negative slope, one per channel or one for all (same parameter name and shape as nn.PReLU)."""
+
+    def forward(self, x):
+        return ops.prelu(ops.as_activation(x, act_dtype(x)) if x.dim() == 4 else x, self.weight)
+
+
 class Hardswish(tnn.Hardswish):
     def forward(self, x):
         return ops.activation(x, _lib.ACT_HSWISH)

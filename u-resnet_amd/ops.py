@@ -1117,6 +1117,43 @@ def activation(x, act, slope=0.0):
     return _Act.apply(x, act, float(slope))
 
 
+class _PReLU(Function):
+    """nn.PReLU: slope per channel (weight.numel() == C) or shared (1); activations are NHWC or [rows][C]."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _require_gpu(x)
+        c = x.shape[1]
+        if weight.numel() not in (1, c):
+            raise RuntimeError("Mismatch of parameter numbers and input channel size. Found parameter numbers = %d and channel size = %d."
+                               % (weight.numel(), c))
+        if x.dim() == 4:
+            x = _g(x)
+        y = torch.empty_like(x, memory_format=CL) if x.dim() == 4 else torch.empty_like(x)
+        call("ur_prelu_fwd", x.data_ptr(), weight.data_ptr(), weight.numel(), y.data_ptr(), _dt(x), x.numel(), c, _stream())
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        c = x.shape[1]
+        g = _g(g) if g.dim() == 4 else g.contiguous()
+        dx = torch.empty_like(g, memory_format=CL) if g.dim() == 4 else torch.empty_like(g)
+        terms = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
+        call("ur_prelu_bwd", g.data_ptr(), x.data_ptr(), weight.data_ptr(), weight.numel(), dx.data_ptr(), terms.data_ptr(), _dt(x),
+             x.numel(), c, _stream())
+        if weight.numel() == 1:
+            dw = _colsum(terms.data_ptr(), _lib.UR_F32, x.numel(), 1, 1, x.device)
+        else:
+            dw = _colsum(terms.data_ptr(), _lib.UR_F32, x.numel() // c, c, c, x.device)
+        return dx, dw.view_as(weight)
+
+
+def prelu(x, weight):
+    return _PReLU.apply(x, weight)
+
+
 class _Add(Function):
     """out = a + b (residual add outside a fused BN epilogue)."""
 
