@@ -309,7 +309,7 @@ def main():
                 "conv3x3_wide_kernel<3> (the same with the BatchNorm-backward sums in the epilogue)": ("wide_dgrad_bn",),
                 "conv_igemm_kernel (generic implicit GEMM: stem, 1x1, ConvT, skinny layers)": ("igemm_fwd", "igemm_dgrad", "pw_fwd", "pw_dgrad"),
                 "wgrad3x3_strip_kernel (3x3 s1 p1 backward-weight; the timed launches include its slab reduction)": ("tile_wgrad",),
-                "conv_wgrad_kernel (generic backward-weight + slab reduce)": ("wgrad",),
+                "conv_wgrad_kernel (generic backward-weight + slab reduce) and the streaming 1x1 backward-weight kernel": ("wgrad", "pw_wgrad"),
             }
             summary = {}
             for name, tags in groups.items():

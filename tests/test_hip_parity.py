@@ -165,6 +165,61 @@ def test_pointwise_kernel_matches_generic_kernel_and_torch(pkg, shape):
     assert rel_l2(res[True][0], yr) < 1e-2 and rel_l2(res[True][1], xr.grad) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(1, 80, 256, 256, 19, 0), (2, 32, 201, 179, 16, 0), (1, 128, 256, 257, 64, 0),
+                                   (1, 24, 300, 220, 8, 0)])
+def test_pointwise_backward_weight_streaming_kernel(pkg, shape):
+    """1x1 stride-1 bf16 layers with few channels on large images take the streaming backward-weight kernel
+    (ur_conv1x1_pw_wgrad): against torch on the same bf16 operands (fp32 accumulation: 1e-4) and against the generic
+    split-K GEMM (1e-5).  Shapes: the segmentation head (19 -> 24 padded gradient channels), a pixel count that is not a
+    multiple of the 32-pixel chunk, the 128 -> 64 instantiation, partly filled 16-channel blocks."""
+    n, cin, h, w, cout, extra = shape
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = bf16_round(torch.randn(n, cin, h, w, generator=g))
+    wt = bf16_round(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    gy = bf16_round(torch.randn(n, cout, h, w, generator=g))
+    wr = wt.clone().requires_grad_(True)
+    (F.conv2d(x, wr) * gy).sum().backward()
+    res = {}
+    for pw in (True, False):
+        pkg.ops.use_pw_kernel = pw
+        pkg.ops.kernel_timings = []
+        try:
+            wd = wt.to(DEV).requires_grad_(True)
+            xa = pkg.ops.as_activation(x.to(DEV), torch.bfloat16)
+            y, _ = pkg.ops.conv2d(xa, wd, None, pkg.ops.PackedWeights(), 1, 0)
+            (y.float() * pkg.ops.to_nhwc_raw(gy.to(DEV), torch.float32)).sum().backward()
+            res[pw] = wd.grad.cpu()
+        finally:
+            tags, pkg.ops.kernel_timings, pkg.ops.use_pw_kernel = set(t[0] for t in pkg.ops.kernel_timings), None, True
+        assert ("pw_wgrad" in tags) == pw and ("wgrad" in tags) == (not pw)
+    assert res[True].shape == wr.grad.shape
+    assert rel_l2(res[True], wr.grad) < 1e-4
+    assert rel_l2(res[True], res[False]) < 1e-5
+
+
+def test_pointwise_backward_weight_reads_channel_windows(pkg):
+    """ur_conv1x1_pw_wgrad through the C ABI with both operands as channel windows of wider tensors (pitches in the
+    descriptor): the gradient of the EUCB projection arrives as a window of the merged tensor's gradient."""
+    import ctypes as C
+    lib = pkg._lib
+    n, h, w, cin, cout = 1, 256, 300, 32, 16
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    gy = torch.randn(n, h, w, cout, generator=g).to(torch.bfloat16)
+    ref = torch.einsum("nhwo,nhwi->oi", gy.double(), x.double())
+    xw = torch.full((n, h, w, cin + 48), 3.0, dtype=torch.bfloat16, device=DEV)
+    xw[..., 16:16 + cin] = x.to(DEV)
+    gw = torch.full((n, h, w, cout + 64), -2.0, dtype=torch.bfloat16, device=DEV)
+    gw[..., 40:40 + cout] = gy.to(DEV)
+    d = lib.ConvDesc(lib.UR_BF16, n, h, w, cin, h, w, cout, 1, 1, 1, 0, cin + 48, cout + 64)
+    assert lib.query("ur_conv1x1_pw_wgrad_supported", C.byref(d)) == 1
+    ws = torch.empty(lib.query("ur_conv1x1_pw_wgrad_workspace", C.byref(d)), dtype=torch.uint8, device=DEV)
+    dw = torch.full((cout, cin), float("nan"), device=DEV)
+    lib.call("ur_conv1x1_pw_wgrad", xw[..., 16:].data_ptr(), gw[..., 40:].data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+             C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rel_l2(dw.cpu(), ref) < 1e-5
+
+
 def test_specialised_kernels_randomised_against_generic(pkg, monkeypatch):
     """60 random shapes (ragged images, channel windows, 32-multiple and odd channel counts): the streaming 1x1 kernel
     and the tiled 3x3 kernel against the generic implicit GEMM on identical bf16 operands (tools/stress_parity.py)."""

@@ -39,6 +39,9 @@ SIGNATURES = {
     "ur_conv1x1_pw_supported": (_i, [_dp, _i]),
     "ur_conv1x1_pw_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _dp, _vp]),
     "ur_conv1x1_pw_dgrad": (_i, [_vp, _vp, _i, _i, _vp, _dp, _vp]),
+    "ur_conv1x1_pw_wgrad_supported": (_i, [_dp]),
+    "ur_conv1x1_pw_wgrad_workspace": (_sz, [_dp]),
+    "ur_conv1x1_pw_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
     "ur_conv2d_wgrad_workspace": (_sz, [_dp]),
     "ur_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
     "ur_conv3x3_tile_supported": (_i, [_dp, _i]),

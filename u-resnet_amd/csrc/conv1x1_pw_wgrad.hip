@@ -1,0 +1,232 @@
+// Backward-weight of the pointwise (1x1, stride 1) bf16 convolutions with few channels on full-resolution activations
+// (segmentation head 80 -> 19, EUCB projection 32 -> 16, the 128 -> 64 shortcut; reference
+// Segmentation/Cityscapes/modules/U_ResNet.py:53-55,127-133):  dW[co][ci] = sum over pixels of dy[p][co] * x[p][ci].
+//
+// A few FLOP per byte: the kernel is a stream over the pixels.  The generic backward-weight GEMM pads these 16..64 x 32..128
+// channel products to 128 x 128 tiles, eight times the matrix work and a third below the memory rate.  Here
+//   * a wave owns 32-pixel chunks and never meets another wave in the loop: it fetches the chunk's x and dy rows as
+//     consecutive 16-byte pieces (the next chunk's loads are in flight while the current one is multiplied), parks them in
+//     its own LDS rows (odd pitch) and reads both back transposed (ds_read_b64_tr_b16: the reduction index is the pixel,
+//     memory is channel-contiguous) as operands of v_mfma_f32_16x16x32_bf16, K = the chunk's 32 pixels;
+//   * the accumulators (16 x 16 blocks of dW) stay in registers for the whole kernel; at the end the four waves of a
+//     workgroup are summed in wave order through LDS and the workgroup writes one fp32 slab; a second kernel sums the
+//     slabs in a fixed order (bitwise reproducible) and writes dW in PyTorch's [cout][cin] layout.
+#include "ur_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+struct PwWgParams {
+    const bf16_t* x;     // [P][ld_x], K channels used
+    const bf16_t* dy;    // [P][ld_dy], M channels used
+    float* ws;           // [workgroups][16 MB][16 KB]
+    long long P;
+    int K, M, ld_x, ld_dy, pitch_x, pitch_y;
+};
+
+int odd_pitch(int bytes) {
+    int q = bytes / 16 + 1;
+    if (!(q & 1)) ++q;
+    return q * 16;
+}
+
+// MB / KB = 16-channel blocks of dy / x that the instantiation covers (M <= 16 MB, K <= 16 KB; rows beyond M or K are zero)
+template <int MB, int KB>
+__global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* xt = lds + (size_t)wave * 32 * (p.pitch_x + p.pitch_y);
+    unsigned char* yt = xt + 32 * p.pitch_x;
+
+    // pieces of a chunk: id = i * 64 + lane -> (pixel, 8-channel group); the same for every chunk
+    const int gx = p.K >> 3, gy = p.M >> 3;
+    constexpr int XL = KB, YL = MB;                       // loads per lane: 32 * gx <= 64 KB pieces, 32 * gy <= 64 MB
+    int xpix[XL], xsrc[XL], xlds[XL], ypix[YL], ysrc[YL], ylds[YL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int id = i * 64 + lane, pix = id / gx, grp = id - pix * gx;
+        xpix[i] = id < 32 * gx ? pix : 1 << 20;
+        xsrc[i] = pix * p.ld_x + grp * 8;
+        xlds[i] = pix * p.pitch_x + grp * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < YL; ++i) {
+        const int id = i * 64 + lane, pix = id / gy, grp = id - pix * gy;
+        ypix[i] = id < 32 * gy ? pix : 1 << 20;
+        ysrc[i] = pix * p.ld_dy + grp * 8;
+        ylds[i] = pix * p.pitch_y + grp * 16;
+    }
+    // transposing reads: 16-lane group g covers pixels 8g + q (+4 for the second read), lane = 4q + c4 addresses channels
+    // 4 c4 .. 4 c4 + 3 of a 16-channel block; afterwards lane j of the group holds channel j, pixels 8g .. 8g+7
+    const int g = lane >> 4, li = lane & 15;
+    const int tpix = 8 * g + (li >> 2), tch = 4 * (li & 3);
+    const unsigned xr = (unsigned)(size_t)xt + tpix * p.pitch_x + tch * 2, yr = (unsigned)(size_t)yt + tpix * p.pitch_y + tch * 2;
+    auto frag = [](unsigned a, int second) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)a);
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)(a + second));
+        const s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, both);
+    };
+
+    f32x4_t acc[MB][KB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const long long chunks = (p.P + 31) / 32;
+    const long long step = (long long)gridDim.x * (NT / 64);
+    long long c = (long long)blockIdx.x * (NT / 64) + wave;
+    bf16x8_t xv[XL], yv[YL];
+    auto fetch = [&](long long chunk) {
+        const long long first = chunk * 32;
+        const int live = (int)(p.P - first < 32 ? p.P - first : 32);
+        const bf16_t* xb = p.x + first * p.ld_x;
+        const bf16_t* yb = p.dy + first * p.ld_dy;
+#pragma unroll
+        for (int i = 0; i < XL; ++i)
+            xv[i] = xpix[i] < live ? *reinterpret_cast<const bf16x8_t*>(xb + xsrc[i]) : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < YL; ++i)
+            yv[i] = ypix[i] < live ? *reinterpret_cast<const bf16x8_t*>(yb + ysrc[i]) : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    // channel groups beyond K / M inside the last 16-channel block are never written: zero the tiles once
+    for (int i = lane; i < 32 * (p.pitch_x + p.pitch_y) / 16; i += 64)
+        *reinterpret_cast<bf16x8_t*>(xt + i * 16) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < chunks) fetch(c);
+    for (; c < chunks; c += step) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // the previous chunk's operand reads are done
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < XL; ++i)
+            if (xpix[i] < 32) *reinterpret_cast<bf16x8_t*>(xt + xlds[i]) = xv[i];
+#pragma unroll
+        for (int i = 0; i < YL; ++i)
+            if (ypix[i] < 32) *reinterpret_cast<bf16x8_t*>(yt + ylds[i]) = yv[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (c + step < chunks) fetch(c + step);
+        bf16x8_t af[MB];
+#pragma unroll
+        for (int a = 0; a < MB; ++a) af[a] = frag(yr + a * 32, 4 * p.pitch_y);
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const bf16x8_t bf = frag(xr + b * 32, 4 * p.pitch_x);
+#pragma unroll
+            for (int a = 0; a < MB; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf, acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- the four waves' blocks, summed in wave order, -> one slab per workgroup ------------------------------------------
+    float* red = reinterpret_cast<float*>(lds);
+    constexpr int NOUT = MB * 16 * KB * 16;
+    for (int w = 0; w < NT / 64; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < MB; ++a)
+#pragma unroll
+                for (int b = 0; b < KB; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int idx = (a * 16 + 4 * g + i) * (KB * 16) + b * 16 + li;
+                        red[idx] = (w == 0 ? 0.f : red[idx]) + acc[a][b][i];
+                    }
+        }
+    }
+    __syncthreads();
+    float* slab = p.ws + (size_t)blockIdx.x * NOUT;
+    for (int i = threadIdx.x; i < NOUT; i += NT) slab[i] = red[i];
+}
+
+// dw[co][ci] = sum_s ws[s][co][ci] over the [16 MB][16 KB] slabs (co < w_cout, ci < w_cin are written)
+template <int SL>
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int rows, int cols,
+                                                              int w_cout, int w_cin, int nslab) {
+    long long idx;
+    float t;
+    if (!ur_slab_sum<SL>(ws, (long long)rows * cols, nslab, idx, t)) return;
+    const int co = (int)(idx / cols), ci = (int)(idx - (long long)co * cols);
+    if (co < w_cout && ci < w_cin) dw[(size_t)co * w_cin + ci] = t;
+}
+
+bool shape_ok(const ur_conv_desc* d) {
+    return d && d->dtype == UR_BF16 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->oh == d->h && d->ow == d->w &&
+           d->cin % 8 == 0 && d->cout % 8 == 0 && d->in_ld % 8 == 0 && d->out_ld % 8 == 0;
+}
+
+// the instantiations: (cout blocks, cin blocks) of 16 channels
+struct Cfg { int mb, kb; };
+bool pick(const ur_conv_desc* d, Cfg& c) {
+    static const Cfg all[] = {{1, 2}, {2, 2}, {2, 5}, {2, 6}, {4, 8}};
+    for (const Cfg& k : all)
+        if (d->cout <= 16 * k.mb && d->cin <= 16 * k.kb) { c = k; return true; }
+    return false;
+}
+
+// LDS rows hold whole 16-channel blocks (the transposing reads fetch them whole; channels beyond K / M stay zero)
+size_t lds_bytes(const Cfg& c) {
+    const size_t stage = (size_t)(NT / 64) * 32 * (odd_pitch(c.kb * 32) + odd_pitch(c.mb * 32));
+    const size_t red = (size_t)c.mb * 16 * c.kb * 16 * sizeof(float);
+    return stage > red ? stage : red;
+}
+
+constexpr int PW_WG_GRID = 512;                       // two workgroups per CU; one slab each
+
+}  // namespace
+
+extern "C" {
+
+int ur_conv1x1_pw_wgrad_supported(const ur_conv_desc* d) {
+    Cfg c;
+    // (worth it where the generic GEMM's 128 x 128 tile is mostly padding and the tensors are large enough to stream)
+    return shape_ok(d) && pick(d, c) && (long long)d->n * d->h * d->w >= 1 << 16;
+}
+
+size_t ur_conv1x1_pw_wgrad_workspace(const ur_conv_desc* d) {
+    Cfg c;
+    if (!shape_ok(d) || !pick(d, c)) return 0;
+    return (size_t)PW_WG_GRID * c.mb * 16 * c.kb * 16 * sizeof(float);
+}
+
+int ur_conv1x1_pw_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
+                        ur_stream_t s) {
+    Cfg c;
+    UR_REQUIRE(shape_ok(d) && pick(d, c), "conv1x1_pw_wgrad: needs bf16, 1x1 stride 1, 8 | channels and pitches, cout <= 64, cin <= 128");
+    UR_REQUIRE(x && dy && dw && workspace, "conv1x1_pw_wgrad: null pointer");
+    UR_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv1x1_pw_wgrad: tensors must be 16-byte aligned");
+    UR_REQUIRE(ws_bytes >= ur_conv1x1_pw_wgrad_workspace(d), "conv1x1_pw_wgrad: workspace too small");
+    PwWgParams p{};
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.ws = (float*)workspace;
+    p.P = (long long)d->n * d->h * d->w;
+    p.K = d->cin; p.M = d->cout; p.ld_x = d->in_ld; p.ld_dy = d->out_ld;
+    p.pitch_x = odd_pitch(c.kb * 32); p.pitch_y = odd_pitch(c.mb * 32);
+    UR_REQUIRE(p.P * (p.ld_x > p.ld_dy ? p.ld_x : p.ld_dy) < (1LL << 31), "conv1x1_pw_wgrad: tensor exceeds 2^31 elements");
+    const size_t lds = lds_bytes(c);
+    const long long chunks = (p.P + 31) / 32;
+    int grid = PW_WG_GRID;
+    if (chunks < (long long)grid * (NT / 64)) grid = (int)((chunks + NT / 64 - 1) / (NT / 64));
+    hipStream_t st = (hipStream_t)s;
+#define UR_PW_WG(MB, KB) hipLaunchKernelGGL((pw_wgrad_kernel<MB, KB>), dim3(grid), dim3(NT), lds, st, p)
+    if (c.mb == 1) UR_PW_WG(1, 2);
+    else if (c.mb == 2 && c.kb == 2) UR_PW_WG(2, 2);
+    else if (c.mb == 2 && c.kb == 5) UR_PW_WG(2, 5);
+    else if (c.mb == 2) UR_PW_WG(2, 6);
+    else UR_PW_WG(4, 8);
+#undef UR_PW_WG
+    if (int e = ur_check_launch("conv1x1_pw_wgrad")) return e;
+    const int rows = c.mb * 16, cols = c.kb * 16;
+    const long long per = (long long)rows * cols;
+    if (ur_slab_lanes(grid) == 32)
+        hipLaunchKernelGGL(pw_wgrad_reduce_kernel<32>, dim3(ur_slab_grid(per, 32)), dim3(256), 0, st, p.ws, dw, rows, cols, d->cout,
+                           d->cin, grid);
+    else
+        hipLaunchKernelGGL(pw_wgrad_reduce_kernel<8>, dim3(ur_slab_grid(per, 8)), dim3(256), 0, st, p.ws, dw, rows, cols, d->cout,
+                           d->cin, grid);
+    return ur_check_launch("conv1x1_pw_wgrad_reduce");
+}
+
+}  // extern "C"

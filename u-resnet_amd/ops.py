@@ -523,6 +523,11 @@ class _Conv2d(Function):
                 with _Timed("tile_wgrad", _conv_flops(d), d):
                     call("ur_wgrad3x3_tile", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
                          C.byref(d), _stream())
+            elif use_pw_kernel and query("ur_conv1x1_pw_wgrad_supported", C.byref(d)):
+                ws = _workspace(query("ur_conv1x1_pw_wgrad_workspace", C.byref(d)), x.device)
+                with _Timed("pw_wgrad", _conv_flops(d), d):
+                    call("ur_conv1x1_pw_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                         C.byref(d), _stream())
             else:
                 ws = _workspace(query("ur_conv2d_wgrad_workspace", C.byref(d)), x.device)
                 with _Timed("wgrad", _conv_flops(d), d):
