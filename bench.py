@@ -265,7 +265,7 @@ def main():
     def timed_steps(fn, with_events):
         if with_events and not args.no_kernel_timing:
             ops.kernel_timings = []
-            ops.kernel_timing_tags = None if args.all_kernel_timing else {"tile_fwd", "tile_dgrad", "tile_dgrad_bn", "wide_fwd", "wide_dgrad", "wide_dgrad_bn", "tile_wgrad"}
+            ops.kernel_timing_tags = None if args.all_kernel_timing else {"tile_fwd", "tile_dgrad", "tile_dgrad_bn", "wide_fwd", "wide_dgrad", "wide_dgrad_bn", "tile_wgrad", "tile_wgrad32"}
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss, _ = fn()
@@ -309,6 +309,7 @@ def main():
                 "conv3x3_wide_kernel<3> (the same with the BatchNorm-backward sums in the epilogue)": ("wide_dgrad_bn",),
                 "conv_igemm_kernel (generic implicit GEMM: stem, 1x1, ConvT, skinny layers)": ("igemm_fwd", "igemm_dgrad", "pw_fwd", "pw_dgrad"),
                 "wgrad3x3_strip_kernel (3x3 s1 p1 backward-weight; the timed launches include its slab reduction)": ("tile_wgrad",),
+                "wgrad32_kernel (3x3 backward-weight of the layers with 32 channels on a side)": ("tile_wgrad32",),
                 "conv_wgrad_kernel (generic backward-weight + slab reduce) and the streaming 1x1 backward-weight kernel": ("wgrad", "pw_wgrad"),
             }
             summary = {}

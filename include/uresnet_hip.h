@@ -86,8 +86,8 @@ int ur_conv1x1_pw_fwd(const void* x, const float* w, int w_cout, int w_cin, cons
 int ur_conv1x1_pw_dgrad(const void* dy, const float* w, int w_cout, int w_cin, void* dx, const ur_conv_desc* d,
                         ur_stream_t s);
 /* backward-weight of the same layers (same contract as ur_conv2d_wgrad: dw fp32 [cout][cin], fixed summation order):
- * a stream over the pixels with the 16..64 x 32..128 channel product on the matrix cores, instead of the generic GEMM's
- * 128 x 128 tiles.  Needs 8 | channels and pitches, cout <= 64, cin <= 128. */
+ * a stream over the pixels with the 16..32 x 32..96 channel product on the matrix cores, instead of the generic GEMM's
+ * 128 x 128 tiles.  Needs 8 | channels and pitches, cout <= 32, cin <= 96. */
 int ur_conv1x1_pw_wgrad_supported(const ur_conv_desc* d);
 size_t ur_conv1x1_pw_wgrad_workspace(const ur_conv_desc* d);
 int ur_conv1x1_pw_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,

@@ -1,0 +1,14 @@
+# Regenerates the measurement artefacts of the default workload in one GPU session (outputs under gpurun_out/final/):
+#   bash tools/final_profiles.sh
+set -e
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout -k 10 300 python bench.py --all-kernel-timing --no-cpu-baseline --per-shape --per-shape-top 90 > $O/bench_all.json 2> $O/per_shape.txt
+timeout -k 10 300 python bench.py --graph --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
+timeout -k 10 300 python bench.py --ddp-single --no-cpu-baseline > $O/bench_ddp_single.json 2> $O/bench_ddp_single.err
+bash tools/ab_bench.sh URESNET_WIDE 2 > $O/ab_wide.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python3 $R/bench.py --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err
+cd $R && bash tools/pmc_bench.sh

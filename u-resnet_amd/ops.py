@@ -520,7 +520,8 @@ class _Conv2d(Function):
             dw = grad_buffer(weight, (d.cout, d.cin, d.kh, d.kw))
             if tile_w:
                 ws = _workspace(query("ur_wgrad3x3_tile_workspace", C.byref(d)), x.device)
-                with _Timed("tile_wgrad", _conv_flops(d), d):
+                # (supported == 2: the 32 x 32-block kernel for layers with 32 channels on a side)
+                with _Timed("tile_wgrad" if tile_w == 1 else "tile_wgrad32", _conv_flops(d), d):
                     call("ur_wgrad3x3_tile", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
                          C.byref(d), _stream())
             elif use_pw_kernel and query("ur_conv1x1_pw_wgrad_supported", C.byref(d)):
