@@ -1,3 +1,6 @@
+"""Streaming 1x1 backward-weight kernel (ur_conv1x1_pw_wgrad) against the generic split-K GEMM (ur_conv2d_wgrad) on the
+network's skinny full-resolution layers; the last tuple element is the channel pitch of x (a window of a wider tensor).
+URESNET_PW_WGRAD_WGS=<n> sets the number of workgroups (= slabs) of the streaming kernel."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, "/root/repo")
 import uresnet_amd
