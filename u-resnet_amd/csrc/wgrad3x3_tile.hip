@@ -219,10 +219,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_strip_kernel(WgTileParam
     constexpr int TH = 2;
     constexpr int HP = M16 ? HPITCH2 : HPITCH;
     constexpr int DY_PIX = TH * TW, DY_BYTES = DY_PIX * 128, HALO_BYTES = 4 * HP * 128;
-    constexpr int DY_ITERS = DY_PIX * 8 / NTHREADS;                                  // 2
-    constexpr int ROW_PIECES = HALO_COLS * 8;                                        // 272 16-byte pieces per halo row
-    constexpr int HALO_ITERS = (4 * ROW_PIECES + NTHREADS - 1) / NTHREADS;           // 5 (all four rows), 3 cover two
-    constexpr int HALO_ITERS2 = (2 * ROW_PIECES + NTHREADS - 1) / NTHREADS;
+    static_assert(NTHREADS == TW * 8, "one thread per 16-byte piece of a 32-pixel row of 64 channels");
     __shared__ __attribute__((aligned(16))) unsigned char lds[DY_BYTES + HALO_BYTES];
     unsigned char* dyl = lds;
     unsigned char* xl = lds + DY_BYTES;
@@ -240,50 +237,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_strip_kernel(WgTileParam
     const int per = (p.tiles + p.nsplit - 1) / p.nsplit;
     const int l0 = split * per, l1 = (l0 + per < p.tiles) ? l0 + per : p.tiles;
 
-    bf16x8_t pd[DY_ITERS], ph[HALO_ITERS];
-    // rows [first_row, 4) of the halo of tile (img, tx, ty): first_row = 0 at the start of a strip run, else 2
+    // Staging pieces (16 bytes = 8 channels of one pixel).  Main pieces: thread -> pixel column tid >> 3 of the tile, one
+    // piece per tile row / halo row, so a row is one load per thread at a per-thread constant offset from a uniform row
+    // address, and its LDS address is a per-thread constant plus a uniform row offset (row pitches of the LDS images are
+    // multiples of the swizzle period).  Tail pieces: halo columns 32 and 33, 16 pieces per row, threads 0..63.
+    const int col = tid >> 3;
+    const unsigned lds_main = (unsigned)sw(col, piece_ch);
+    const unsigned dy_voff = (unsigned)(col * p.ld_dy + piece_ch) * 2u, x_voff = (unsigned)(col * p.ld_x + piece_ch) * 2u;
+    const int trow = tid >> 4, tcol = TW + ((tid >> 3) & 1);
+    const bf16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    bf16x8_t pd[TH], ph[5];
+    // rows [row0, 4) of the halo of tile (img, tx, ty): row0 = 0 at the start of a strip run, else 2 (ph[j] = row row0 + j)
     auto prefetch = [&](int l, bool full) {
         const int ty = l % p.tiles_y, rest = l / p.tiles_y;
         const int tx = rest % p.tiles_x, img = rest / p.tiles_x;
         const int ty0 = ty * TH, tx0 = tx * TW;
-        const bf16_t* dyb = p.dy + (size_t)img * p.H * p.W * p.ld_dy + co0 + piece_ch;
-        const bf16_t* xb = p.x + (size_t)img * p.H * p.W * p.ld_x + ci0 + piece_ch;
-#pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) {
-            const int pix = (tid >> 3) + j * (NTHREADS / 8);
-            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
-            if (oy < p.H && ox < p.W) pd[j] = *reinterpret_cast<const bf16x8_t*>(dyb + ((size_t)oy * p.W + ox) * p.ld_dy);
-            else pd[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        }
         const int row0 = full ? 0 : 2;
+        const long long dy_row = ((long long)(img * p.H + ty0) * p.W + tx0) * p.ld_dy + co0;
+        const char* dyb = reinterpret_cast<const char*>(p.dy) + dy_row * 2;
+        const bool dcol_ok = tx0 + col < p.W;
 #pragma unroll
-        for (int j = 0; j < HALO_ITERS; ++j) {
-            if (j < HALO_ITERS2 || full) {
-                const int hp = (tid >> 3) + j * (NTHREADS / 8);
-                const int hy = hp / HALO_COLS, hx = hp - hy * HALO_COLS;
-                const int gy = ty0 - 1 + row0 + hy, gx = tx0 - 1 + hx;
-                if (row0 + hy < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                    ph[j] = *reinterpret_cast<const bf16x8_t*>(xb + ((size_t)gy * p.W + gx) * p.ld_x);
-                else ph[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < TH; ++j) {
+            if (ty0 + j < p.H && dcol_ok)
+                pd[j] = *reinterpret_cast<const bf16x8_t*>(dyb + (size_t)j * p.W * p.ld_dy * 2 + dy_voff);
+            else pd[j] = zero8;
+        }
+        // address of halo row row0, halo column 0; only dereferenced where the pixel exists
+        const long long x_row = ((long long)(img * p.H + ty0 - 1 + row0) * p.W + tx0 - 1) * p.ld_x + ci0;
+        const char* xb = reinterpret_cast<const char*>(p.x) + x_row * 2;
+        const bool xcol_ok = (unsigned)(tx0 - 1 + col) < (unsigned)p.W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < 2 || full) {
+                if ((unsigned)(ty0 - 1 + row0 + j) < (unsigned)p.H && xcol_ok)
+                    ph[j] = *reinterpret_cast<const bf16x8_t*>(xb + (size_t)j * p.W * p.ld_x * 2 + x_voff);
+                else ph[j] = zero8;
             }
         }
+        if (trow < 4 - row0 && (unsigned)(ty0 - 1 + row0 + trow) < (unsigned)p.H && (unsigned)(tx0 - 1 + tcol) < (unsigned)p.W)
+            ph[4] = *reinterpret_cast<const bf16x8_t*>(xb + (((size_t)trow * p.W + tcol) * p.ld_x + piece_ch) * 2);
+        else ph[4] = zero8;
     };
     // k = parity of the tile's position in its strip run: halo row hr of the tile lives in ring slot (hr + 2k) & 3
     auto commit = [&](int k, bool full) {
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) {
-            const int pix = (tid >> 3) + j * (NTHREADS / 8);
-            *reinterpret_cast<bf16x8_t*>(dyl + sw(pix, piece_ch)) = pd[j];
-        }
+        for (int j = 0; j < TH; ++j) *reinterpret_cast<bf16x8_t*>(dyl + j * TW * 128 + lds_main) = pd[j];
         const int row0 = full ? 0 : 2;
 #pragma unroll
-        for (int j = 0; j < HALO_ITERS; ++j) {
-            if (j < HALO_ITERS2 || full) {
-                const int hp = (tid >> 3) + j * (NTHREADS / 8);
-                const int hy = hp / HALO_COLS, hx = hp - hy * HALO_COLS;
-                const int slot = (row0 + hy + 2 * k) & 3;
-                if (row0 + hy < 4) *reinterpret_cast<bf16x8_t*>(xl + sw(slot * HP + hx, piece_ch)) = ph[j];
+        for (int j = 0; j < 4; ++j) {
+            if (j < 2 || full) {
+                const int slot = (row0 + j + 2 * k) & 3;
+                *reinterpret_cast<bf16x8_t*>(xl + slot * HP * 128 + lds_main) = ph[j];
             }
+        }
+        if (trow < 4 - row0) {
+            const int slot = (row0 + trow + 2 * k) & 3;
+            *reinterpret_cast<bf16x8_t*>(xl + sw(slot * HP + tcol, piece_ch)) = ph[4];
         }
     };
 
