@@ -109,6 +109,19 @@ def test_conv2d_fwd_bwd(pkg, shape, dtype):
     assert rel_l2(st[:, 1], (yf * yf).sum((0, 2, 3))) < 5e-3 + tol
 
 
+def test_empty_batch_is_rejected_with_a_message(pkg):
+    """An empty batch never reaches a kernel: the library refuses the descriptor and says why (the reference's training
+    forward fails on an empty batch as well, in its first BatchNorm)."""
+    import ctypes as C
+    with pytest.raises(pkg._lib.UResNetHipError, match="bad arguments|non-positive"):
+        pkg.ops.as_activation(torch.zeros(0, 64, 8, 8, device=DEV), torch.bfloat16)      # the layout conversion already refuses
+    d = pkg._lib.ConvDesc(pkg._lib.UR_BF16, 0, 8, 8, 64, 8, 8, 64, 3, 3, 1, 1, 64, 64)
+    buf = torch.zeros(64 * 64 * 9, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(pkg._lib.UResNetHipError, match="non-positive"):
+        pkg._lib.call("ur_conv2d_fwd", buf.data_ptr(), buf.data_ptr(), None, buf.data_ptr(), None, C.byref(d),
+                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
 def test_tiled_3x3_kernel_agrees_with_generic_kernel(pkg):
     """The LDS-tiled bf16 3x3 kernel and the generic implicit-GEMM kernel see identical bf16 inputs and
     accumulate in fp32: they must agree to fp32 summation-order round-off (then one bf16 rounding)."""
