@@ -1,4 +1,4 @@
-# A/B of two library builds on the default workload, interleaved: bash tools/_ab_lib.sh <other.so> [rounds]
+# A/B of two library builds on the default workload, interleaved: bash tools/ab_lib.sh <other.so> [rounds]
 R=$GRAFT_REPO_ROOT; cd $R
 for i in $(seq 1 ${2:-3}); do
   for v in base other; do
