@@ -303,6 +303,25 @@ struct Chan8 {
 // bf16, 8 channels per thread (16-byte accesses).  The grid stride is a multiple of C for the power-of-two
 // channel counts of the network, so a thread keeps its 8 channels for the whole walk (FIXED): constants are
 // loaded once and UNROLL independent 16-byte loads are in flight per tensor before the first use.
+// 16-byte accesses of the streaming passes, non-temporal: every byte of these tensors is touched once per pass and the
+// tensors are many times the size of the L2.  Measured on a plain copy of 384 MiB: 5.9 TB/s with ordinary accesses, 6.4 TB/s
+// non-temporal; on the training step of the default workload 31.15 -> 30.53 ms (loads 1.2 %, loads and stores 2.0 %).
+// -DUR_NT_LOAD=0 / -DUR_NT_STORE=0 build the ordinary forms for A/B runs.
+#ifndef UR_NT_LOAD
+#define UR_NT_LOAD 1
+#endif
+#ifndef UR_NT_STORE
+#define UR_NT_STORE 1
+#endif
+__device__ __forceinline__ bf16x8_t ld_stream(const bf16_t* p) {
+    const bf16x8_t* q = reinterpret_cast<const bf16x8_t*>(p);
+    return UR_NT_LOAD ? __builtin_nontemporal_load(q) : *q;
+}
+__device__ __forceinline__ void st_stream(bf16_t* p, const bf16x8_t& v) {
+    bf16x8_t* q = reinterpret_cast<bf16x8_t*>(p);
+    if (UR_NT_STORE) __builtin_nontemporal_store(v, q); else *q = v;
+}
+
 #ifndef UR_EW_UNROLL
 #define UR_EW_UNROLL 4
 #endif
@@ -334,15 +353,15 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __r
             if (act) o = fmaxf(o, 0.f);
             o8[v] = (bf16_t)o;
         }
-        *reinterpret_cast<bf16x8_t*>(z + zi) = o8;
+        st_stream(z + zi, o8);
     };
     if (FIXED) {
         for (; i + (EW_UNROLL - 1) * stride < total; i += EW_UNROLL * stride, zoff += EW_UNROLL * zstep) {
             bf16x8_t y8[EW_UNROLL], r8[EW_UNROLL];
 #pragma unroll
             for (int u = 0; u < EW_UNROLL; ++u) {
-                y8[u] = *reinterpret_cast<const bf16x8_t*>(y + i + u * stride);
-                if (RES) r8[u] = *reinterpret_cast<const bf16x8_t*>(res + i + u * stride); else r8[u] = y8[u];
+                y8[u] = ld_stream(y + i + u * stride);
+                if (RES) r8[u] = ld_stream(res + i + u * stride); else r8[u] = y8[u];
             }
 #pragma unroll
             for (int u = 0; u < EW_UNROLL; ++u) one(y8[u], r8[u], zoff + u * zstep);
@@ -356,9 +375,9 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __r
             cnext += cstep;
             if (cnext >= C) { cnext -= C; zoff += z_ld - C; }
         }
-        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
+        const bf16x8_t y8 = ld_stream(y + i);
         bf16x8_t r8 = y8;
-        if (RES) r8 = *reinterpret_cast<const bf16x8_t*>(res + i);
+        if (RES) r8 = ld_stream(res + i);
         one(y8, r8, zi);
     }
 }
@@ -462,8 +481,8 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
             const float o = eval ? kk * gv : kk * (gv - s0[v] - xh * s1[v]);
             o8[v] = (bf16_t)o; r8[v] = (bf16_t)gv;
         }
-        *reinterpret_cast<bf16x8_t*>(dy + i) = o8;
-        if (DRES) *reinterpret_cast<bf16x8_t*>(dres + i) = r8;
+        st_stream(dy + i, o8);
+        if (DRES) st_stream(dres + i, r8);
     };
     long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8;
     if (FIXED) {
@@ -472,9 +491,9 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
             bf16x8_t g8[U], y8[U], z8[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                g8[u] = *reinterpret_cast<const bf16x8_t*>(dz + goff + u * gstep);
-                y8[u] = *reinterpret_cast<const bf16x8_t*>(y + i + u * stride);
-                if (HAVE_Z) z8[u] = *reinterpret_cast<const bf16x8_t*>(z + i + u * stride); else z8[u] = g8[u];
+                g8[u] = ld_stream(dz + goff + u * gstep);
+                y8[u] = ld_stream(y + i + u * stride);
+                if (HAVE_Z) z8[u] = ld_stream(z + i + u * stride); else z8[u] = g8[u];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) one(g8[u], y8[u], z8[u], i + u * stride);
@@ -488,10 +507,10 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_bf16x8_kernel(
             cnext += cstep;
             if (cnext >= C) { cnext -= C; goff += dz_ld - C; }
         }
-        const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(dz + gi);
-        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(y + i);
+        const bf16x8_t g8 = ld_stream(dz + gi);
+        const bf16x8_t y8 = ld_stream(y + i);
         bf16x8_t z8 = g8;
-        if (HAVE_Z) z8 = *reinterpret_cast<const bf16x8_t*>(z + i);
+        if (HAVE_Z) z8 = ld_stream(z + i);
         one(g8, y8, z8, i);
     }
 }
@@ -541,18 +560,18 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_bf16x8_kernel(
         bf16x8_t g8[U], y8[U], z8[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            g8[u] = *reinterpret_cast<const bf16x8_t*>(pg + u * gstep);
-            y8[u] = *reinterpret_cast<const bf16x8_t*>(py + u * ystep);
-            if (HAVE_Z) z8[u] = *reinterpret_cast<const bf16x8_t*>(pz + u * ystep); else z8[u] = g8[u];
+            g8[u] = ld_stream(pg + u * gstep);
+            y8[u] = ld_stream(py + u * ystep);
+            if (HAVE_Z) z8[u] = ld_stream(pz + u * ystep); else z8[u] = g8[u];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) one(g8[u], y8[u], z8[u]);
     }
     for (; r < rows; r += step, py += ystep, pz += ystep, pg += gstep) {
-        const bf16x8_t g8 = *reinterpret_cast<const bf16x8_t*>(pg);
-        const bf16x8_t y8 = *reinterpret_cast<const bf16x8_t*>(py);
+        const bf16x8_t g8 = ld_stream(pg);
+        const bf16x8_t y8 = ld_stream(py);
         bf16x8_t z8 = g8;
-        if (HAVE_Z) z8 = *reinterpret_cast<const bf16x8_t*>(pz);
+        if (HAVE_Z) z8 = ld_stream(pz);
         one(g8, y8, z8);
     }
 #pragma unroll
