@@ -15,6 +15,10 @@
 //   grid = one resident round of 4-wave workgroups; a wave takes chunks wave_id, wave_id + waves, ...
 #include "ur_common.h"
 
+// tensors streamed once per launch go through non-temporal accesses (0.2 % of the training step); -DUR_PW_NT=0: ordinary
+#ifndef UR_PW_NT
+#define UR_PW_NT 1
+#endif
 namespace {
 
 constexpr int NT = 256;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
         const int live = (int)(p.P - first < 32 ? p.P - first : 32);
 #pragma unroll
         for (int i = 0; i < KS; ++i)
-            dst[i] = ipix[i] < live ? *reinterpret_cast<const bf16x8_t*>(src + isrc[i]) : zero;
+            dst[i] = ipix[i] < live ? (UR_PW_NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(src + isrc[i])) : *reinterpret_cast<const bf16x8_t*>(src + isrc[i])) : zero;
     };
 
     bf16x8_t nxt[KS];
@@ -174,7 +178,11 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
             bf16_t* out = p.y + first * p.out_ld;
 #pragma unroll
             for (int i = 0; i < NO; ++i)
-                if (opix[i] < live) *reinterpret_cast<bf16x8_t*>(out + odst[i]) = *reinterpret_cast<const bf16x8_t*>(lout + olds[i]);
+                if (opix[i] < live) {
+                    const bf16x8_t o8 = *reinterpret_cast<const bf16x8_t*>(lout + olds[i]);
+                    if (UR_PW_NT) __builtin_nontemporal_store(o8, reinterpret_cast<bf16x8_t*>(out + odst[i]));
+                    else *reinterpret_cast<bf16x8_t*>(out + odst[i]) = o8;
+                }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -18,6 +18,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// tensors streamed once per launch go through non-temporal accesses (0.2 % of the training step); -DUR_IGEMM_NT=0: ordinary
+#ifndef UR_IGEMM_NT
+#define UR_IGEMM_NT 1
+#endif
 namespace {
 
 constexpr int BM = 256;
@@ -371,7 +375,10 @@ __global__ __launch_bounds__(NTHREADS, (BN <= 64 && sizeof(T) == 2) ? 3 : (sizeo
                         const int tap = nn / p.cout_t, co = nn - tap * p.cout_t;
                         off = rowoff[i] + ((size_t)(tap >> 1) * (2 * p.OW) + (tap & 1)) * p.dst_ld + co;
                     }
-                    *reinterpret_cast<float4*>(dst + off) = *reinterpret_cast<const float4*>(stage + row * PITCH + piece * VE);
+                    typedef __attribute__((ext_vector_type(4))) float raw16_t;
+                    const raw16_t piece16 = *reinterpret_cast<const raw16_t*>(stage + row * PITCH + piece * VE);
+                    if (UR_IGEMM_NT) __builtin_nontemporal_store(piece16, reinterpret_cast<raw16_t*>(dst + off));     // written once, read by the next kernel
+                    else *reinterpret_cast<raw16_t*>(dst + off) = piece16;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
