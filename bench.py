@@ -402,6 +402,7 @@ def main():
                        {"buckets": len(ddp.buckets), "bucket_order": ddp.bucket_order_source,
                         "gradient_fraction_written_in_place_by_the_kernels":
                             round(ddp.in_place_elems / max(1, ddp.in_place_elems + ddp.copied_elems), 4)},
+                       "branch_streams": ({"second_stream_probe": list(ops.stream_probe_log)} if ops.branch_streams else None),
                        "step_launch": "one HIP graph replay per step" if graphed is not None else "eager (about 460 launches per step)"},
             "roofline": roof,
             "cpu_baseline": cpu,

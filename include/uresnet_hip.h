@@ -281,6 +281,11 @@ int ur_act_bwd(const void* dy, const void* x, void* dx, int dtype, long long cou
 int ur_prelu_fwd(const void* x, const float* slope, int nslope, void* y, int dtype, long long count, int c, ur_stream_t s);
 int ur_prelu_bwd(const void* dy, const void* x, const float* slope, int nslope, void* dx, float* slope_terms, int dtype,
                  long long count, int c, ur_stream_t s);
+/* One idle wave that occupies stream s for `microseconds` (1..100000) and touches no memory.  No counterpart in the
+ * reference: the host side uses it once per device to find a second stream whose launches really run beside the first one's
+ * (two streams that the runtime maps onto one hardware queue execute in order), before it puts the ResBlock branch of a
+ * two-branch network (S/C:262-280: the branches meet only at the Feature Merge) on that stream. */
+int ur_spin(int microseconds, ur_stream_t s);
 /* a += b (gradient accumulation at forks), elementwise over `count` elements */
 int ur_add_inplace(void* a, const void* b, int dtype, long long count, ur_stream_t s);
 /* layout / dtype conversion at the model boundary */

@@ -1195,3 +1195,42 @@ def test_seg_model_ragged_size_matches_oracle(pkg, oracle, base_c, dtype):
         # bf16 storage of every activation: gradient norms drift by percents through 40 layers (the reference's own
         # bf16-autocast run drifts 0.3-0.46 on gradients); the median pins the bulk, NaN/garbage would fail both
         assert np.median(errs) < 5e-2 and max(errs) < 0.5, (np.median(errs), max(errs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls_name", ["UResNetNewEUCB", "UResNet", "UResNetNoEUCB"])
+def test_two_stream_branches_match_the_single_stream_step_bit_exactly(pkg, cls_name):
+    """The ResBlock branch of the two-branch networks (S/C:262-280: the branches meet only at the Feature Merge) runs on a
+    second stream by default.  Same kernels on the same data in another order of issue: losses, logits and every weight
+    after several Adam steps equal the single-stream run bit for bit -- over batches of changing size, so that memory freed
+    by one branch is reused while the other branch is still queued (the hand-overs between the streams are what is tested).
+    UResNetNoEUCB merges through a copy (its upsampled tensor is made on the second stream and read on the first)."""
+    M, train, ops = pkg.modules.U_ResNet, pkg.train, pkg.ops
+
+    def run(two_streams):
+        old, ops.branch_streams = ops.branch_streams, two_streams
+        try:
+            torch.manual_seed(0)
+            m = getattr(M, cls_name)(19, 3, 8).set_compute_dtype(torch.bfloat16).to(DEV).train()
+            opt = train.Adam(m.parameters(), lr=1e-3)
+            g = torch.Generator().manual_seed(7)
+            losses = []
+            for hw in [(32, 64), (64, 64), (32, 32), (64, 128), (32, 64), (64, 64)]:
+                x = torch.randn(2, 3, *hw, generator=g).to(DEV)
+                y = torch.randint(0, 19, (2,) + hw, generator=g)
+                y[torch.rand(y.shape, generator=g) < 0.1] = 255
+                losses.append(train.seg_train_step(m, opt, x, y.to(DEV))[0].item())
+            m.eval()
+            with torch.no_grad():
+                logits = m(torch.randn(2, 3, 32, 64, generator=g).to(DEV)).float().clone()
+            torch.cuda.synchronize()
+            return losses, logits, [v.clone() for v in m.state_dict().values()]
+        finally:
+            ops.branch_streams = old
+
+    one, two = run(False), run(True)
+    assert one[0] == two[0]
+    assert torch.equal(one[1], two[1])
+    for a, b in zip(one[2], two[2]):
+        assert torch.equal(a, b)
+    assert ops.stream_probe_log, "the second stream is chosen by measurement"

@@ -103,6 +103,7 @@ SIGNATURES = {
     "ur_prelu_fwd": (_i, [_vp, _vp, _i, _vp, _i, _ll, _i, _vp]),
     "ur_prelu_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _ll, _i, _vp]),
     "ur_add_inplace": (_i, [_vp, _vp, _i, _ll, _vp]),
+    "ur_spin": (_i, [_i, _vp]),
     "ur_nchw_to_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ur_pack_image_u8": (_i, [_vp, _vp, _i, _ll, _i, _i, _vp, _vp, _i, _vp]),
     "ur_remap_labels_u8": (_i, [_vp, _vp, _ll, _vp, _vp]),

@@ -585,6 +585,14 @@ __global__ __launch_bounds__(NT) void remap_labels_kernel(const uint8_t* __restr
         else hipLaunchKernelGGL((kernel<T, 1>), dim3(ur_grid_1d((total), NT)), dim3(NT), 0, (hipStream_t)s, __VA_ARGS__);        \
     })
 
+namespace {
+// One wave that does nothing until `ticks` of the constant 100 MHz counter have passed (time-bounded: it always ends).
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+
 extern "C" {
 
 int ur_maxpool2x2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int n, int h, int w, int c, int x_ld, ur_stream_t s) {
@@ -698,6 +706,12 @@ int ur_channel_shuffle(const void* x, void* y, int dtype, long long rows, int c,
     UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_shuffle_kernel<T>), dim3(ur_grid_1d(total, NT)), dim3(NT), 0,
                                                 (hipStream_t)s, (const T*)x, (T*)y, rows, c, groups));
     return ur_check_launch("channel_shuffle");
+}
+
+int ur_spin(int microseconds, ur_stream_t s) {
+    UR_REQUIRE(microseconds > 0 && microseconds <= 100000, "spin: 1..100000 microseconds");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (long long)microseconds * 100);
+    return ur_check_launch("spin");
 }
 
 int ur_add_inplace(void* a, const void* b, int dtype, long long count, ur_stream_t s) {

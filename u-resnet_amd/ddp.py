@@ -28,6 +28,7 @@ class _Bucket:
         self.pending = len(params)
         self.work = None
         self.had_grad = [False] * len(params)
+        self.events = {}            # stream handle -> event recorded after the last gradient that stream delivered
 
     def view(self, i):
         p = self.params[i]
@@ -107,6 +108,16 @@ class DataParallel:
 
     # -- gradient buckets ---------------------------------------------------------------------
     def _launch(self, b):
+        if not b.flat.is_cuda:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
+        # A network whose branches run on two streams delivers the gradients of one bucket from both.  The collective is
+        # ordered after the stream this hook runs on; that stream first waits for the other stream's LAST DELIVERY into
+        # this bucket (an event recorded when it arrived), not for everything the other branch has queued since.
+        cur = torch.cuda.current_stream(b.flat.device)
+        for handle, ev in b.events.items():
+            if handle != cur.cuda_stream:
+                cur.wait_event(ev)
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
@@ -123,6 +134,12 @@ class DataParallel:
             self.in_place_elems += p.numel()
         b.had_grad[i] = True
         b.pending -= 1
+        if slot.is_cuda:
+            cur = torch.cuda.current_stream(slot.device)
+            ev = b.events.get(cur.cuda_stream)
+            if ev is None:
+                ev = b.events[cur.cuda_stream] = torch.cuda.Event()
+            ev.record(cur)
         if b.pending == 0 and self._checked:         # the first step launches from finish(), after the consistency check
             self._launch(b)
 

@@ -7,6 +7,8 @@ tensor already in the compute dtype); returns logits of logical shape [B, seg_cl
 channels-last memory and the model's compute dtype (`set_compute_dtype`, default
 uresnet_amd.get_default_dtype()).
 """
+import contextlib
+
 from .. import nn as hnn
 from .. import ops
 from ._blocks import (BasicBlock, Bottleneck, DoubleConv, Down, EUCB, EUCB2, OutConv, ResTrunk, Up,  # noqa: F401
@@ -39,7 +41,12 @@ class _TwoBranch(ResTrunk):
 
     def forward(self, x):
         x = ops.as_activation(x, self.compute_dtype)
-        res = self._res_forward(x)
+        # the two branches only meet at the Feature Merge: with ops.branch_streams the ResBlock branch is launched on a
+        # second stream, so its kernels fill the compute units the UBlock branch's kernels leave idle (and vice versa)
+        fork = ops.BranchFork(x) if (ops.branch_streams and x.is_cuda) else None
+        on_side = fork.branch if fork is not None else contextlib.nullcontext
+        with on_side():
+            res = self._res_forward(x)
         n, _, h, w = x.shape
         c_u, c_res = self.up4.conv[3].out_channels, self.out_conv[0].num_features - self.up4.conv[3].out_channels
         if (isinstance(self.Upsample, (EUCB, EUCB2)) and not has_hooks(self.Upsample, self.up4, self.up4.conv)
@@ -48,13 +55,19 @@ class _TwoBranch(ResTrunk):
             # tensor (S/C:280 torch.cat([u_out, res_out], dim=1))
             cat = ops.empty_nhwc(n, c_u + c_res, h, w, x.dtype, x.device)
             wu, wr = ops.alias_window(cat, 0, c_u), ops.alias_window(cat, c_u, c_res)
-            res_out = self.Upsample(res, out=wr)
+            with on_side():
+                res_out = self.Upsample(res, out=wr)
             u_out = unet_branch_forward(self, x, out=wu)
+            if fork is not None:
+                fork.join(res_out)
             if u_out.data_ptr() == wu.data_ptr() and res_out.data_ptr() == wr.data_ptr():
                 return self.out_conv(ops.cat_windows(u_out, res_out, cat))
             return self.out_conv(ops.cat_pad(ops.dense(u_out), ops.dense(res_out)))
-        res_out = self.Upsample(res)
+        with on_side():
+            res_out = self.Upsample(res)
         u_out = unet_branch_forward(self, x)
+        if fork is not None:
+            fork.join(res_out)
         return self.out_conv(ops.cat_pad(u_out, res_out))
 
 

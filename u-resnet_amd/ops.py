@@ -229,6 +229,74 @@ def _repack_stale_tile_images(device):
         pw._cache[mode] = (new_key, packed)
 
 
+# Two-branch networks launch their ResBlock branch on a second stream (URESNET_BRANCH_STREAMS=0: everything on one stream).
+branch_streams = os.environ.get("URESNET_BRANCH_STREAMS", "1") != "0"
+_side_streams = {}
+stream_probe_log = []       # what _concurrent_stream measured (one line per candidate stream)
+
+
+def _concurrent_stream(main, tries=8, spin_us=300):
+    """A stream whose launches run beside those of `main`.  The runtime maps streams onto a few hardware queues (four
+    per process by default) and two streams on one queue execute in order, so which stream is independent of `main`
+    depends on what else the process has created (communicator streams, torch's pools).  Measured, not assumed: an idle
+    wave of `spin_us` on `main` and one on the candidate take one spin time together if the two overlap and two if
+    they do not.  Falls back to the last candidate (correct, merely not concurrent) when none overlaps."""
+    dev = main.device
+    cand = torch.cuda.Stream(dev)
+    if torch.cuda.is_current_stream_capturing():
+        return cand
+    for _ in range(tries):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        call("ur_spin", 1, main.cuda_stream)          # first launches on a stream pay for its set-up: not measured
+        call("ur_spin", 1, cand.cuda_stream)
+        torch.cuda.synchronize(dev)
+        e0.record(main)
+        call("ur_spin", spin_us, main.cuda_stream)
+        call("ur_spin", spin_us, cand.cuda_stream)
+        e1.record(main)
+        e2.record(cand)
+        torch.cuda.synchronize(dev)
+        stream_probe_log.append("candidate %d: %.3f / %.3f ms for two %d us idle waves"
+                                % (_, e0.elapsed_time(e1), e0.elapsed_time(e2), spin_us))
+        if max(e0.elapsed_time(e1), e0.elapsed_time(e2)) < 1.5e-3 * spin_us:
+            break
+        cand = torch.cuda.Stream(dev)
+    return cand
+
+
+class BranchFork:
+    """Launch one of two independent branches of a network on a second stream.
+
+        fork = BranchFork(x)            # x: tensors made on the current stream that the side branch reads
+        with fork.branch(): a = side_branch(x)
+        b = main_branch(x)
+        fork.join(a)                    # the current stream waits; tensors made on the side stream are handed over
+
+    Backward needs nothing: autograd runs every node on the stream its forward ran on and orders the streams itself.
+    Weight images that went stale with the last optimiser step are rebuilt before the fork, on the current stream: the
+    rebuild is one launch for all layers, so whichever branch triggered it would race with the other."""
+
+    def __init__(self, *shared):
+        dev = shared[0].device
+        self.main = torch.cuda.current_stream(dev)
+        self.side = _side_streams.get((dev, self.main.cuda_stream))
+        if self.side is None:
+            self.side = _side_streams[(dev, self.main.cuda_stream)] = _concurrent_stream(self.main)
+        if batch_repack:
+            _repack_stale_tile_images(dev)
+        self.side.wait_stream(self.main)
+        for t in shared:                       # their memory must not be reused while side-stream launches are pending
+            t.record_stream(self.side)
+
+    def branch(self):
+        return torch.cuda.stream(self.side)
+
+    def join(self, *made_on_side):
+        self.main.wait_stream(self.side)
+        for t in made_on_side:
+            t.record_stream(self.main)
+
+
 class PackedWeights:
     """Per-layer cache of the weight matrices the GEMM kernels consume (activation dtype, k-major)."""
 
@@ -329,8 +397,9 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
-def _colsum(t2d_ptr, dtype_code, rows, c, ld, device):
-    out = torch.empty(c, dtype=torch.float32, device=device)
+def _colsum(t2d_ptr, dtype_code, rows, c, ld, device, param=None):
+    """Column sums of a rows x c matrix; `param`: the bias these are the gradient of (see grad_buffer)."""
+    out = torch.empty(c, dtype=torch.float32, device=device) if param is None else grad_buffer(param, (c,))
     ws = _workspace(query("ur_colsum_workspace", rows, c), device)
     call("ur_colsum", t2d_ptr, dtype_code, rows, c, ld, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     return out
@@ -420,7 +489,7 @@ class _Conv2d(Function):
                  d.n, cout, _dt(y), _stream())
             y = out[0]
         ctx.save_for_backward(x, weight)          # x: as the kernel saw it (channel-padded on the generic path)
-        ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
+        ctx.d, ctx.packs, ctx.has_bias, ctx.bias = d, packs, bias is not None, bias
         ctx.bn_rec = getattr(x_in, "_ur_bn", None) if tile else None
         ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
         # alias of the input for a second consumer (the shortcut of a residual block): its gradient comes back to this
@@ -453,7 +522,7 @@ class _Conv2d(Function):
         else:
             dy = _g(dy)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, cout, d.out_ld, x.device)
+            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, cout, d.out_ld, x.device, ctx.bias)
         if cout % 8 and not (tile_d and tile_w):
             dy = _pad_channels(dy, _pad8(cout))
             d = _desc(x.shape, _pad8(cout), d.kh, d.kw, d.stride, d.pad, x.dtype)
@@ -603,7 +672,7 @@ class _ConvT2x2(Function):
         with _Timed("igemm_fwd", _conv_flops(d, True), d):
             call("ur_convT2x2_fwd", x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), C.byref(d), _stream())
         ctx.save_for_backward(x, weight)
-        ctx.d, ctx.packs, ctx.has_bias = d, packs, bias is not None
+        ctx.d, ctx.packs, ctx.has_bias, ctx.bias = d, packs, bias is not None, bias
         return y
 
     @staticmethod
@@ -624,7 +693,7 @@ class _ConvT2x2(Function):
                 call("ur_convT2x2_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
                      C.byref(d), _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, d.cout, d.cout, x.device)
+            db = _colsum(dy.data_ptr(), d.dtype, d.n * d.oh * d.ow, d.cout, d.cout, x.device, ctx.bias)
         return dx, dw, db, None
 
 
@@ -657,7 +726,7 @@ class _ConvT2x2Cat(Function):
         if buf is None:
             _copy_channels(skip, 0, cs, out, 0)
         ctx.save_for_backward(x, weight)
-        ctx.d, ctx.packs, ctx.has_bias, ctx.cs = d, packs, bias is not None, cs
+        ctx.d, ctx.packs, ctx.has_bias, ctx.cs, ctx.bias = d, packs, bias is not None, cs, bias
         return out
 
     @staticmethod
@@ -678,7 +747,7 @@ class _ConvT2x2Cat(Function):
             with _Timed("wgrad", _conv_flops(d, True), d):
                 call("ur_convT2x2_wgrad", x.data_ptr(), dy_ptr, dw.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(d), _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy_ptr, d.dtype, d.n * d.oh * d.ow, d.cout, d.out_ld, x.device)
+            db = _colsum(dy_ptr, d.dtype, d.n * d.oh * d.ow, d.cout, d.out_ld, x.device, ctx.bias)
         if ctx.needs_input_grad[4]:
             # a channel window of g, not a copy: the skip tensor has a second consumer, so autograd adds this to
             # the other gradient in one pass; a lone consumer densifies it through _g()
@@ -840,8 +909,7 @@ class _BNAct(Function):
         if rec is not None:
             rec.partial = None
         sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
-        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        dgamma, dbeta = grad_buffer(gamma), grad_buffer(beta)
         call("ur_bn_bwd_finalize", partial.data_ptr(), nparts, c, sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
              _stream())
         dy = torch.empty_like(y, memory_format=CL)
