@@ -193,6 +193,9 @@ def main():
         sys.exit(self_launch(args))
     if args.rehearse_cpu:
         return rehearse_cpu(args)
+    if os.environ.get("URESNET_BENCH_DUMP_AFTER"):          # a hung rank prints every thread's stack and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["URESNET_BENCH_DUMP_AFTER"]), exit=True)
     import torch
     import torch.distributed as dist
     import uresnet_amd
@@ -283,8 +286,15 @@ def main():
     final_loss = float(loss.item())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    spread = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # replicas must stay identical: largest difference of any weight between any two ranks (outside the timed region)
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = float((hi - lo).abs().max().item())
     elapsed = float(t.item())
 
     if rank == 0:
@@ -400,6 +410,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
                        "data_parallel_wrapper": None if ddp is None else
                        {"buckets": len(ddp.buckets), "bucket_order": ddp.bucket_order_source,
+                        "max_weight_difference_between_ranks": spread,
                         "gradient_fraction_written_in_place_by_the_kernels":
                             round(ddp.in_place_elems / max(1, ddp.in_place_elems + ddp.copied_elems), 4)},
                        "branch_streams": ({"second_stream_probe": list(ops.stream_probe_log)} if ops.branch_streams else None),

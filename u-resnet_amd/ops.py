@@ -235,30 +235,34 @@ _side_streams = {}
 stream_probe_log = []       # what _concurrent_stream measured (one line per candidate stream)
 
 
-def _concurrent_stream(main, tries=8, spin_us=300):
-    """A stream whose launches run beside those of `main`.  The runtime maps streams onto a few hardware queues (four
-    per process by default) and two streams on one queue execute in order, so which stream is independent of `main`
-    depends on what else the process has created (communicator streams, torch's pools).  Measured, not assumed: an idle
-    wave of `spin_us` on `main` and one on the candidate take one spin time together if the two overlap and two if
-    they do not.  Falls back to the last candidate (correct, merely not concurrent) when none overlaps."""
-    dev = main.device
+def _overlaps(a, b, spin_us=300):
+    """True if an idle wave on stream a and one on stream b run side by side (one spin time for both, not two)."""
+    dev = a.device
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    call("ur_spin", 1, a.cuda_stream)          # first launches on a stream pay for its set-up: not measured
+    call("ur_spin", 1, b.cuda_stream)
+    torch.cuda.synchronize(dev)
+    e0.record(a)
+    call("ur_spin", spin_us, a.cuda_stream)
+    call("ur_spin", spin_us, b.cuda_stream)
+    e1.record(a)
+    e2.record(b)
+    torch.cuda.synchronize(dev)
+    stream_probe_log.append("%.3f / %.3f ms for two %d us idle waves" % (e0.elapsed_time(e1), e0.elapsed_time(e2), spin_us))
+    return max(e0.elapsed_time(e1), e0.elapsed_time(e2)) < 1.5e-3 * spin_us
+
+
+def _concurrent_stream(*others, tries=8):
+    """A stream whose launches run beside those of every stream in `others`.  The runtime maps streams onto a few hardware
+    queues (four per process by default) and two streams on one queue execute in order, so which stream is independent
+    of another depends on what else the process has created (communicator streams, torch's pools).  Measured, not
+    assumed.  Falls back to the last candidate (correct, merely not concurrent) when none overlaps."""
+    dev = others[0].device
     cand = torch.cuda.Stream(dev)
     if torch.cuda.is_current_stream_capturing():
         return cand
     for _ in range(tries):
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        call("ur_spin", 1, main.cuda_stream)          # first launches on a stream pay for its set-up: not measured
-        call("ur_spin", 1, cand.cuda_stream)
-        torch.cuda.synchronize(dev)
-        e0.record(main)
-        call("ur_spin", spin_us, main.cuda_stream)
-        call("ur_spin", spin_us, cand.cuda_stream)
-        e1.record(main)
-        e2.record(cand)
-        torch.cuda.synchronize(dev)
-        stream_probe_log.append("candidate %d: %.3f / %.3f ms for two %d us idle waves"
-                                % (_, e0.elapsed_time(e1), e0.elapsed_time(e2), spin_us))
-        if max(e0.elapsed_time(e1), e0.elapsed_time(e2)) < 1.5e-3 * spin_us:
+        if all(_overlaps(o, cand) for o in others):
             break
         cand = torch.cuda.Stream(dev)
     return cand
