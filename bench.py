@@ -282,8 +282,20 @@ def main():
         loss, host_elapsed, elapsed, timings = timed_steps(step, True)
     else:
         loss, host_elapsed, elapsed, _ = timed_steps(lambda: graphed(x, y), False)
-        _, _, eager_elapsed, timings = timed_steps(step, True)      # kernel events: eager re-run, outside the timed region
+        keep, ops.branch_streams = ops.branch_streams, False    # kernel events: eager re-run on one stream, outside the timed region
+        _, _, eager_elapsed, timings = timed_steps(step, True)
+        ops.branch_streams = keep
     final_loss = float(loss.item())
+    # With the two branches on two streams a kernel shares the chip with the other stream's kernels while it runs: the
+    # time between its two events is no longer its own.  The per-kernel numbers of `roofline` therefore come from the
+    # same steps run once more on ONE stream right after the timed region; what the events showed inside the timed
+    # region is kept next to them (`in_timed_region`), and `value` / `ms_per_step` are the timed region's alone.
+    concurrent_timings, isolated_elapsed = None, None
+    if ops.branch_streams and timings and graphed is None:
+        concurrent_timings = timings
+        ops.branch_streams = False
+        _, _, isolated_elapsed, timings = timed_steps(step, True)
+        ops.branch_streams = True
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     spread = None
@@ -299,15 +311,20 @@ def main():
 
     if rank == 0:
         peak = BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else FP32_MATRIX_PEAK_TFLOPS
-        kernels = {}
-        shapes = {}
-        for tag, flops, e0, e1, shape in (timings or []):
-            sk = shapes.setdefault((tag, shape), [0, 0.0, 0.0])
-            sk[0] += 1; sk[1] += flops; sk[2] += e0.elapsed_time(e1) * 1e-3
-            k = kernels.setdefault(tag, [0, 0.0, 0.0])
-            k[0] += 1
-            k[1] += flops
-            k[2] += e0.elapsed_time(e1) * 1e-3
+        def fold(tm):
+            kernels, shapes = {}, {}
+            for tag, flops, e0, e1, shape in (tm or []):
+                sk = shapes.setdefault((tag, shape), [0, 0.0, 0.0])
+                sk[0] += 1; sk[1] += flops; sk[2] += e0.elapsed_time(e1) * 1e-3
+                k = kernels.setdefault(tag, [0, 0.0, 0.0])
+                k[0] += 1
+                k[1] += flops
+                k[2] += e0.elapsed_time(e1) * 1e-3
+            return kernels, shapes
+        kernels, shapes = fold(timings)
+        step_elapsed = elapsed                      # time shares refer to the pass the events were recorded in
+        if concurrent_timings is not None:
+            step_elapsed = isolated_elapsed
         roof = None
         if kernels:
             groups = {
@@ -330,7 +347,7 @@ def main():
                 if n:
                     summary[name] = {"achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4),
                                      "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
-                                     "flops_per_launch": fl / n, "time_share_of_step": round(sec / elapsed, 3)}
+                                     "flops_per_launch": fl / n, "time_share_of_step": round(sec / step_elapsed, 3)}
             dominant = max(summary, key=lambda k: summary[k]["time_share_of_step"])
             dom = summary.pop(dominant)
             traffic = source = None
@@ -357,9 +374,28 @@ def main():
                                         "frac": round(kernels[t][1] / kernels[t][2] / 1e12 / peak, 4),
                                         "avg_launch_ms": round(kernels[t][2] / kernels[t][0] * 1e3, 4)}
                                     for t in groups[dominant] if t in kernels},
-                    "timing_region": ("the timed steps" if graphed is None else
-                                      "the same %d steps run eagerly right after the timed graph replays (%.3f ms per step)"
-                                      % (args.steps, eager_elapsed / args.steps * 1e3))}
+                    "timing_region": (("the timed steps" if concurrent_timings is None else
+                                       "the same %d steps run on ONE stream right after the timed region (%.3f ms per step): in the "
+                                       "timed region the two branches of the network run on two streams and every kernel shares "
+                                       "the chip with the other stream's, so its event-to-event time is not its own"
+                                       % (args.steps, isolated_elapsed / args.steps * 1e3)) if graphed is None else
+                                      "the same %d steps run eagerly on one stream right after the timed graph replays "
+                                      "(%.3f ms per step)" % (args.steps, eager_elapsed / args.steps * 1e3))}
+            if concurrent_timings is not None:
+                ck, _ = fold(concurrent_timings)
+                n = sum(ck[t][0] for t in groups[dominant] if t in ck)
+                fl = sum(ck[t][1] for t in groups[dominant] if t in ck)
+                sec = sum(ck[t][2] for t in groups[dominant] if t in ck)
+                cfl = sum(k[1] for t, k in ck.items() if not t.startswith("hbm:"))
+                roof["in_timed_region"] = {
+                    "note": "event-to-event times of the same kernel while the other stream's kernels run beside it (these agree "
+                            "with a rocprofv3 kernel trace of this command; they overlap, so they do not add up to the step)",
+                    "achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4),
+                    "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
+                    "timed_conv_kernels_flops_over_step_time": {
+                        "achieved": round(cfl / elapsed / 1e12, 2), "frac": round(cfl / elapsed / 1e12 / peak, 4), "unit": "TFLOP/s",
+                        "note": "FLOPs of the convolution launches that carried events, divided by the wall time of the timed "
+                                "region: the matrix-pipe utilisation of the whole step, all other kernels included"}}
             # the 3x3 forward / backward-data launches as one family (two kernels, each with epilogue variants): the numbers
             # comparable with runs that had a single kernel for all of them
             def family(tags):
@@ -368,7 +404,7 @@ def main():
                     return None
                 fl, sec, n = sum(k[1] for k in fam), sum(k[2] for k in fam), sum(k[0] for k in fam)
                 return {"achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4), "launches": n,
-                        "avg_launch_ms": round(sec / n * 1e3, 4), "time_share_of_step": round(sec / elapsed, 3)}
+                        "avg_launch_ms": round(sec / n * 1e3, 4), "time_share_of_step": round(sec / step_elapsed, 3)}
             roof["conv3x3_forward_and_backward_data"] = {
                 "plain_launches": family(("tile_fwd", "tile_dgrad", "wide_fwd", "wide_dgrad")),
                 "launches_that_also_emit_batchnorm_backward_sums": family(("tile_dgrad_bn", "wide_dgrad_bn")),
@@ -379,12 +415,12 @@ def main():
                         "bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4), "launches": n,
                         "avg_launch_ms": round(sec / n * 1e3, 4), "bytes_per_launch": by / n,
-                        "time_share_of_step": round(sec / elapsed, 3)}
+                        "time_share_of_step": round(sec / step_elapsed, 3)}
             conv_flops = sum(k[1] for t, k in kernels.items() if not t.startswith("hbm:"))
             conv_secs = sum(k[2] for t, k in kernels.items() if not t.startswith("hbm:"))
             if args.all_kernel_timing:
                 roof["all_conv_mfma_util"] = round(conv_flops / conv_secs / 1e12 / peak, 4)
-                roof["all_conv_time_share_of_step"] = round(conv_secs / elapsed, 3)
+                roof["all_conv_time_share_of_step"] = round(conv_secs / step_elapsed, 3)
             else:
                 roof["other_kernels_note"] = "run with --all-kernel-timing for the other kernel groups"
         if args.per_shape:
