@@ -1234,3 +1234,33 @@ def test_two_stream_branches_match_the_single_stream_step_bit_exactly(pkg, cls_n
     for a, b in zip(one[2], two[2]):
         assert torch.equal(a, b)
     assert ops.stream_probe_log, "the second stream is chosen by measurement"
+
+
+@pytest.mark.gpu
+def test_two_stream_branches_of_the_classification_nets_match_bit_exactly(pkg):
+    """Same as above for the classification nets, whose U-Net and ResBlock branches meet at the concatenation before the
+    head (C/M:352-364, C/C:232-250): SGD steps on one and on two streams give identical losses and weights."""
+    train, ops = pkg.train, pkg.ops
+    cases = [(pkg.modules.U_ResNet_CIFAR.UResNet4_No_SU, dict(num_classes=10, in_channels=3, scale=3), (8, 3, 32, 32), 10),
+             (pkg.modules.U_ResNet_MiniImageNet.U_ResNet, dict(num_classes=100, in_channels=3), (2, 3, 224, 224), 100)]
+    for cls, kw, shape, classes in cases:
+        def run(two_streams):
+            old, ops.branch_streams = ops.branch_streams, two_streams
+            try:
+                torch.manual_seed(0)
+                m = cls(**kw).set_compute_dtype(torch.bfloat16).to(DEV).train()
+                opt = train.SGD(m.parameters(), lr=0.01)
+                g = torch.Generator().manual_seed(11)
+                losses = []
+                for _ in range(3):
+                    x = torch.randn(*shape, generator=g).to(DEV)
+                    y = torch.randint(0, classes, (shape[0],), generator=g).to(DEV)
+                    losses.append(train.cls_train_step(m, opt, x, y)[0].item())
+                torch.cuda.synchronize()
+                return losses, [v.clone() for v in m.state_dict().values()]
+            finally:
+                ops.branch_streams = old
+        one, two = run(False), run(True)
+        assert one[0] == two[0], cls.__name__
+        for a, b in zip(one[1], two[1]):
+            assert torch.equal(a, b), cls.__name__

@@ -69,8 +69,7 @@ class UResNet4_No_SU(_Cls):
 
     def forward(self, x):
         x = ops.as_activation(x, self.compute_dtype)
-        logits = self.convert(self.U_Net(x))
-        out = self.Upsample(self._res_forward(x))
+        out, logits = ops.two_branches(x, lambda t: self.Upsample(self._res_forward(t)), lambda t: self.convert(self.U_Net(t)))
         return self._head(ops.cat_channels(out, logits), 7)
 
 
@@ -90,8 +89,7 @@ class UResNet3_No_EUCB(_Cls):
 
     def forward(self, x):
         x = ops.as_activation(x, self.compute_dtype)
-        logits = ops.avg_pool2d(self.U_Net(x), 2)
-        out = self._res_forward(x)
+        out, logits = ops.two_branches(x, self._res_forward, lambda t: ops.avg_pool2d(self.U_Net(t), 2))
         return self._head(ops.cat_channels(out, logits), 5)
 
 

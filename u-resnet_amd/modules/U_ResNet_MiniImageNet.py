@@ -97,6 +97,5 @@ class U_ResNet(_Cls):
 
     def forward(self, x):
         x = ops.as_activation(x, self.compute_dtype)
-        logits = self.U_Net(x)
-        out = self.Upsample(self._res_forward(x))
+        out, logits = ops.two_branches(x, lambda t: self.Upsample(self._res_forward(t)), self.U_Net)
         return self._head(ops.cat_channels(out, logits), 7)

@@ -83,8 +83,7 @@ class NlNet(_Temp):
 
     def forward(self, x):
         x = ops.as_activation(x, self.compute_dtype)
-        logits = self.U_Net(x)
-        out = self.Upsample(self._trunk(x))
+        out, logits = ops.two_branches(x, lambda t: self.Upsample(self._trunk(t)), self.U_Net)
         return self._head(ops.cat_channels(out, logits), 9)      # AvgPool2d(kernel_size=9, stride=9), C/T:304,331
 
 
@@ -110,8 +109,8 @@ class E_ResNet(_Temp):
 
     def forward(self, x):
         x = ops.as_activation(x, self.compute_dtype)
-        logits = ops.avg_pool2d(self.U_Net(x), 2)
-        return self._head(ops.cat_channels(self._trunk(x), logits), 7)
+        out, logits = ops.two_branches(x, self._trunk, lambda t: ops.avg_pool2d(self.U_Net(t), 2))
+        return self._head(ops.cat_channels(out, logits), 7)
 
 
 class U_ResNet(_Temp):

@@ -301,6 +301,19 @@ class BranchFork:
             t.record_stream(self.main)
 
 
+def two_branches(x, side_fn, main_fn):
+    """(side_fn(x), main_fn(x)) for two independent branches fed by the same activation: with `branch_streams` the first
+    is launched on the second stream (see BranchFork) and joined before this returns."""
+    if branch_streams and x.is_cuda:
+        fork = BranchFork(x)
+        with fork.branch():
+            a = side_fn(x)
+        b = main_fn(x)
+        fork.join(*(t for t in (a if isinstance(a, (tuple, list)) else (a,)) if torch.is_tensor(t)))
+        return a, b
+    return side_fn(x), main_fn(x)
+
+
 class PackedWeights:
     """Per-layer cache of the weight matrices the GEMM kernels consume (activation dtype, k-major)."""
 
