@@ -179,6 +179,36 @@ def test_config5_ice_seg_inference_mask(pkg, oracle):
         assert (got != want).float().mean().item() < flips       # only logits within round-off of 0 may flip
 
 
+def test_config5_large_batch_inference_equals_small_batches_bit_exactly(pkg):
+    """Config 5 at its large batch (32 x 3 x 512 x 512, the size tools/bench_eval.py times; the CPU oracle would take
+    minutes): eval-mode BatchNorm uses fixed statistics, so every image is independent of its batch -- the logits and
+    masks of one batch of 32 equal those of the same images sent through in batches of 4 bit for bit (tile order, XCD
+    mapping, folded-BatchNorm epilogues and the two-stream forward do not depend on what else is in the batch), and the
+    masks agree with the one-stream forward."""
+    ops = pkg.ops
+    torch.manual_seed(0)
+    m = pkg.modules.U_ResNet.UResNet(1, 3, 64).set_compute_dtype(torch.bfloat16).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    m.train()
+    with torch.no_grad():
+        for _ in range(2):                                  # running statistics away from their initial (0, 1)
+            m(torch.randn(2, 3, 64, 64, generator=g).to(DEV))
+    m.eval()
+    x = torch.randn(32, 3, 512, 512, generator=g).to(DEV)
+    with torch.no_grad():
+        big = m(x)
+        small = torch.cat([m(x[i:i + 4]) for i in range(0, 32, 4)])
+        old, ops.branch_streams = ops.branch_streams, not ops.branch_streams
+        try:
+            other = m(x)
+        finally:
+            ops.branch_streams = old
+    assert torch.equal(big, small)
+    assert torch.equal(big, other)
+    assert torch.isfinite(big.float()).all()
+    assert torch.equal(pkg.train.sigmoid_mask(big), pkg.train.sigmoid_mask(small))
+
+
 def test_config4_full_resolution_1024x2048(pkg, oracle):
     """Config 4: one 1024x2048 image through UResNetNewEUCB(19,3,64).  Forward logits and loss against the oracle (train
     mode, batch statistics; fp32 2e-4, bf16 against the bf16-storage oracle), then properties that need no oracle: the
