@@ -48,14 +48,19 @@ def seg_case(name, build, shape, classes=19, dtype=torch.bfloat16):
     report(name, shape, dtype, dt)
 
 
-def cls_case(name, build, shape, classes, lr, dtype=torch.bfloat16):
+def cls_case(name, build, shape, classes, lr, dtype=torch.bfloat16, graph=False):
     torch.manual_seed(0)
     model = build().set_compute_dtype(dtype).to(DEV).train()
     opt = train.SGD(model.parameters(), lr=lr)
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(*shape, generator=g).to(DEV)
     y = torch.randint(0, classes, (shape[0],), generator=g).to(DEV)
-    dt = timed(lambda: train.cls_train_step(model, opt, x, y))
+    if graph:                                   # the whole step as one HIP graph replay (launch-bound shapes)
+        step = train.GraphedStep(train.cls_train_step, model, opt, x, y, warmup=3)
+        dt = timed(lambda: step(x, y))
+        name += " graph"
+    else:
+        dt = timed(lambda: train.cls_train_step(model, opt, x, y))
     report(name, shape, dtype, dt)
 
 
@@ -70,7 +75,10 @@ def main():
     uresnet_amd._lib.load()
     cls_case("UResNet4_No_SU(10,3,scale=3)", lambda: CC.UResNet4_No_SU(10, 3, scale=3), (64, 3, 32, 32), 10, 0.01, torch.float32)
     cls_case("UResNet4_No_SU(10,3,scale=3)", lambda: CC.UResNet4_No_SU(10, 3, scale=3), (64, 3, 32, 32), 10, 0.01)
+    cls_case("UResNet4_No_SU(10,3,scale=3)", lambda: CC.UResNet4_No_SU(10, 3, scale=3), (64, 3, 32, 32), 10, 0.01, graph=True)
+    cls_case("UResNet4_No_SU(10,3,scale=3)", lambda: CC.UResNet4_No_SU(10, 3, scale=3), (256, 3, 32, 32), 10, 0.01, graph=True)
     cls_case("mini U_ResNet(100,3)", lambda: CM.U_ResNet(100, 3), (32, 3, 224, 224), 100, 0.1)
+    cls_case("mini U_ResNet(100,3)", lambda: CM.U_ResNet(100, 3), (32, 3, 224, 224), 100, 0.1, graph=True)
     cls_case("temp NlNet(100,3)", lambda: CT.NlNet(100, 3), (32, 3, 224, 224), 100, 0.01)
     cls_case("temp UResNet2(100,3)", lambda: CT.UResNet2(100, 3), (32, 3, 224, 224), 100, 0.01)
     seg_case("UResNetNewEUCB(19,3,64)", lambda: S.UResNetNewEUCB(19, 3, 64), (6, 3, 512, 1024))
