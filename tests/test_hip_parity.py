@@ -1264,3 +1264,28 @@ def test_two_stream_branches_of_the_classification_nets_match_bit_exactly(pkg):
         assert one[0] == two[0], cls.__name__
         for a, b in zip(one[1], two[1]):
             assert torch.equal(a, b), cls.__name__
+
+
+@pytest.mark.gpu
+def test_spin_entry_point_and_stream_probe(pkg):
+    """ur_spin parks an idle wave for about the time asked for (it is the yardstick of the stream-concurrency probe),
+    refuses times outside 1..100000 microseconds, and a stream never overlaps itself while the probe's pick overlaps the
+    stream it was picked for."""
+    lib, ops = pkg._lib, pkg.ops
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lib.call("ur_spin", 1, s.cuda_stream)
+    torch.cuda.synchronize()
+    e0.record(s)
+    lib.call("ur_spin", 2000, s.cuda_stream)
+    e1.record(s)
+    torch.cuda.synchronize()
+    assert 1.9 < e0.elapsed_time(e1) < 3.0
+    for bad in (0, -5, 100001):
+        with pytest.raises(lib.UResNetHipError):
+            lib.call("ur_spin", bad, s.cuda_stream)
+    assert not ops._overlaps(s, s)
+    side = ops._concurrent_stream(s)
+    assert side.cuda_stream != s.cuda_stream
+    if any(" 0.3" in line.split("/")[1] for line in ops.stream_probe_log[-8:]):     # a concurrent candidate was found
+        assert ops._overlaps(s, side)
