@@ -794,11 +794,13 @@ class _GConv3x3(Function):
         stats = None
         if rows:          # BatchNorm partial sums from the kernel's epilogue instead of a separate pass over y
             stats = torch.empty((rows, c, 2), dtype=torch.float32, device=x.device)
-            call("ur_gconv3x3_fwd_stats", x.data_ptr(), weight.data_ptr(), y.data_ptr(), stats.data_ptr(), _dt(x), n, h, w, c,
-                 cpg, _stream())
+            with _Timed("hbm:gconv3x3_fwd", 2 * x.numel() * x.element_size()):
+                call("ur_gconv3x3_fwd_stats", x.data_ptr(), weight.data_ptr(), y.data_ptr(), stats.data_ptr(), _dt(x), n, h, w,
+                     c, cpg, _stream())
             ctx.mark_non_differentiable(stats)
         else:
-            call("ur_gconv3x3_fwd", x.data_ptr(), weight.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, cpg, _stream())
+            with _Timed("hbm:gconv3x3_fwd", 2 * x.numel() * x.element_size()):
+                call("ur_gconv3x3_fwd", x.data_ptr(), weight.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, cpg, _stream())
         ctx.save_for_backward(x, weight)
         ctx.set_materialize_grads(False)
         return y, stats
@@ -814,13 +816,15 @@ class _GConv3x3(Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=CL)
-            call("ur_gconv3x3_dgrad", dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _dt(x), n, h, w, c, cpg,
-                 _stream())
+            with _Timed("hbm:gconv3x3_dgrad", 2 * x.numel() * x.element_size()):
+                call("ur_gconv3x3_dgrad", dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _dt(x), n, h, w, c, cpg,
+                     _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = _workspace(query("ur_gconv3x3_wgrad_workspace", n, h, w, c, cpg), x.device)
-            call("ur_gconv3x3_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), _dt(x),
-                 n, h, w, c, cpg, _stream())
+            with _Timed("hbm:gconv3x3_wgrad", 2 * x.numel() * x.element_size()):
+                call("ur_gconv3x3_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), _dt(x),
+                     n, h, w, c, cpg, _stream())
         return dx, dw, None
 
 
@@ -965,8 +969,9 @@ class _MaxPool2x2(Function):
         n, c, h, w = x.shape
         y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
         idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
-        call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _channel_pitch(x) or c,
-             _stream())
+        with _Timed("hbm:maxpool_fwd", x.numel() * x.element_size() + y.numel() * (y.element_size() + 1)):
+            call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _channel_pitch(x) or c,
+                 _stream())
         ctx.save_for_backward(idx)
         ctx.shape = (n, c, h, w)
         return y
@@ -977,7 +982,8 @@ class _MaxPool2x2(Function):
         n, c, h, w = ctx.shape
         dy = _g(dy)
         dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
-        call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), None, 0, _dt(dy), n, h, w, c, _stream())
+        with _Timed("hbm:maxpool_bwd", dx.numel() * dx.element_size() + dy.numel() * (dy.element_size() + 1)):
+            call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), None, 0, _dt(dy), n, h, w, c, _stream())
         return dx
 
 
@@ -995,8 +1001,9 @@ class _MaxPool2x2Skip(Function):
         n, c, h, w = x.shape
         y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
         idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
-        call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _channel_pitch(x) or c,
-             _stream())
+        with _Timed("hbm:maxpool_fwd", x.numel() * x.element_size() + y.numel() * (y.element_size() + 1)):
+            call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _channel_pitch(x) or c,
+                 _stream())
         ctx.save_for_backward(idx)
         ctx.shape = (n, c, h, w)
         ctx.set_materialize_grads(False)
@@ -1017,8 +1024,10 @@ class _MaxPool2x2Skip(Function):
             if not add_ld:
                 dskip, add_ld = _g(dskip), c
         dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
-        call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _p(dskip), add_ld, _dt(dy), n, h, w, c,
-             _stream())
+        with _Timed("hbm:maxpool_bwd", dx.numel() * dx.element_size() * (2 if dskip is not None else 1)
+                    + dy.numel() * (dy.element_size() + 1)):
+            call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _p(dskip), add_ld, _dt(dy), n, h, w, c,
+                 _stream())
         return dx
 
 
@@ -1033,7 +1042,8 @@ class _UpsampleBilinear(Function):
         _require_gpu(x)
         n, c, h, w = x.shape
         y = empty_nhwc(n, c, h * scale, w * scale, x.dtype, x.device)
-        call("ur_upsample_bilinear_fwd", x.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, scale, _stream())
+        with _Timed("hbm:upsample_fwd", (x.numel() + y.numel()) * x.element_size()):
+            call("ur_upsample_bilinear_fwd", x.data_ptr(), y.data_ptr(), _dt(x), n, h, w, c, scale, _stream())
         ctx.shape, ctx.scale = (n, c, h, w), scale
         return y
 
@@ -1042,7 +1052,8 @@ class _UpsampleBilinear(Function):
         n, c, h, w = ctx.shape
         dy = _g(dy)
         dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
-        call("ur_upsample_bilinear_bwd", dy.data_ptr(), dx.data_ptr(), _dt(dy), n, h, w, c, ctx.scale, _stream())
+        with _Timed("hbm:upsample_bwd", (dx.numel() + dy.numel()) * dy.element_size()):
+            call("ur_upsample_bilinear_bwd", dy.data_ptr(), dx.data_ptr(), _dt(dy), n, h, w, c, ctx.scale, _stream())
         return dx, None
 
 
@@ -1288,8 +1299,9 @@ class _CrossEntropy(Function):
         lse = torch.empty(rows, dtype=torch.float32, device=dev)
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
         ws = _workspace(query("ur_loss_workspace", rows), dev)
-        call("ur_ce_fwd", logits.data_ptr(), _dt(logits), target.data_ptr(), rows, c, c, ignore_index, lse.data_ptr(),
-             out3.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        with _Timed("hbm:ce_fwd", logits.numel() * logits.element_size() + rows * 12):      # logits, int64 target, fp32 lse
+            call("ur_ce_fwd", logits.data_ptr(), _dt(logits), target.data_ptr(), rows, c, c, ignore_index, lse.data_ptr(),
+                 out3.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         count = out3[1:2]
         if count_hook is not None:          # data parallel: mean over the GLOBAL number of valid pixels
             count = count_hook(out3)
@@ -1303,8 +1315,9 @@ class _CrossEntropy(Function):
         rows, c, ignore_index = ctx.meta
         gout = gout.contiguous().float()
         dlogits = torch.empty_like(logits, memory_format=torch.preserve_format)
-        call("ur_ce_bwd", logits.data_ptr(), _dt(logits), target.data_ptr(), rows, c, c, ignore_index, lse.data_ptr(),
-             count.data_ptr(), gout.data_ptr(), dlogits.data_ptr(), c, _stream())
+        with _Timed("hbm:ce_bwd", 2 * logits.numel() * logits.element_size() + rows * 12):
+            call("ur_ce_bwd", logits.data_ptr(), _dt(logits), target.data_ptr(), rows, c, c, ignore_index, lse.data_ptr(),
+                 count.data_ptr(), gout.data_ptr(), dlogits.data_ptr(), c, _stream())
         return dlogits, None, None, None
 
 
