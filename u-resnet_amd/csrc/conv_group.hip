@@ -149,13 +149,19 @@ __global__ __launch_bounds__(NT) void gconv3x3_regw_kernel(const T* __restrict__
 //   grid.x = image * row strips * column strips, grid.y = quad blocks of QB = min(Q, 64) quads
 // STATS: also emit per-channel partial sums (sum, sum of squares of the fp32 results) for a following BatchNorm, one
 // row per blockIdx.x: stats[gridDim.x][C][2].
-template <bool DGRAD, bool STATS>
+// NQ = channel quads per lane: 2 where the channel count is a multiple of 8 (16-byte loads and stores; a lane then feeds
+// two matrix instructions per tap, one per quad), else 1.  QB counts such lane units per workgroup.
+template <int NQ> struct GcVec { typedef s16x4_t type; };
+template <> struct GcVec<2> { typedef __attribute__((ext_vector_type(8))) short type; };
+
+template <bool DGRAD, bool STATS, int NQ>
 __global__ __launch_bounds__(NT) void gconv3x3_mfma_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                            bf16_t* __restrict__ out, int H, int W, int C, int QB, int RS,
                                                            int xstrips, int ystrips, float* __restrict__ stats) {
+    typedef typename GcVec<NQ>::type vec_t;
     const int lane4 = threadIdx.x & 3;
     const int gb = threadIdx.x >> 2;                         // 0..63: block index within the workgroup
-    const int q = blockIdx.y * QB + gb % QB;
+    const int u = blockIdx.y * QB + gb % QB;                 // lane unit: quads u * NQ .. u * NQ + NQ - 1
     const int pg = gb / QB;                                  // pixel group within the workgroup
     const int PG = 64 / QB;
     int bid = blockIdx.x;
@@ -167,83 +173,115 @@ __global__ __launch_bounds__(NT) void gconv3x3_mfma_kernel(const bf16_t* __restr
     const int y1 = min(y0 + RS, H);
 
     // weight rows: forward A[i][k] = w[q*4+i][k][tap]; backward-data A[i][k] = w[q*4+k][i][tap]
-    s16x4_t wt[9];
+    s16x4_t wt[NQ][9];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        bf16x4_t v;
+    for (int h = 0; h < NQ; ++h) {
+        const int q = u * NQ + h;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            v[k] = (bf16_t)(DGRAD ? w[((size_t)(q * 4 + k) * 4 + lane4) * 9 + tap] : w[((size_t)(q * 4 + lane4) * 4 + k) * 9 + tap]);
-        wt[tap] = __builtin_bit_cast(s16x4_t, v);
+        for (int tap = 0; tap < 9; ++tap) {
+            bf16x4_t v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = (bf16_t)(DGRAD ? w[((size_t)(q * 4 + k) * 4 + lane4) * 9 + tap] : w[((size_t)(q * 4 + lane4) * 4 + k) * 9 + tap]);
+            wt[h][tap] = __builtin_bit_cast(s16x4_t, v);
+        }
     }
 
     const bool xin = x < W;
     const bool xl = xin && x >= 1, xr = x + 1 < W;
-    const bf16_t* img = in + (size_t)n * H * W * C + q * 4;
-    const s16x4_t zero = {0, 0, 0, 0};
-    auto load_row = [&](int yy, s16x4_t* row) {
+    const bf16_t* img = in + (size_t)n * H * W * C + u * (NQ * 4);
+    vec_t zero;
+#pragma unroll
+    for (int k = 0; k < NQ * 4; ++k) zero[k] = 0;
+    auto load_row = [&](int yy, vec_t* row) {
         const bool yok = (unsigned)yy < (unsigned)H;
         const bf16_t* p = img + ((size_t)yy * W + x) * C;
-        row[0] = (yok && xl) ? *reinterpret_cast<const s16x4_t*>(p - C) : zero;
-        row[1] = (yok && xin) ? *reinterpret_cast<const s16x4_t*>(p) : zero;
-        row[2] = (yok && xr) ? *reinterpret_cast<const s16x4_t*>(p + C) : zero;
+        row[0] = (yok && xl) ? *reinterpret_cast<const vec_t*>(p - C) : zero;
+        row[1] = (yok && xin) ? *reinterpret_cast<const vec_t*>(p) : zero;
+        row[2] = (yok && xr) ? *reinterpret_cast<const vec_t*>(p + C) : zero;
     };
-    s16x4_t win[3][3];
-    float st[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto quad = [&](const vec_t& v, int h) -> s16x4_t {
+        if constexpr (NQ == 1) return v;
+        else return h == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7);
+    };
+    vec_t win[3][3];
+    float st[NQ * 8];
+#pragma unroll
+    for (int k = 0; k < NQ * 8; ++k) st[k] = 0.f;
     load_row(y0 - 1, win[0]);
     load_row(y0, win[1]);
     for (int y = y0; y < y1; ++y) {
         load_row(y + 1, win[2]);
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4_t acc[NQ];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int h = 0; h < NQ; ++h) {
+            acc[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-                acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wt[ky * 3 + kx], DGRAD ? win[2 - ky][2 - kx] : win[ky][kx], acc, 0, 0, 0);
-        if (xin) ur_store4(out + (((size_t)n * H + y) * W + x) * C + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[h] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wt[h][ky * 3 + kx], quad(DGRAD ? win[2 - ky][2 - kx] : win[ky][kx], h),
+                                                                    acc[h], 0, 0, 0);
+        }
+        if (xin) {
+            bf16_t* o = out + (((size_t)n * H + y) * W + x) * C + u * (NQ * 4);
+            if constexpr (NQ == 1) {
+                ur_store4(o, make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]));
+            } else {
+                const bf16x8_t v = {(bf16_t)acc[0][0], (bf16_t)acc[0][1], (bf16_t)acc[0][2], (bf16_t)acc[0][3],
+                                    (bf16_t)acc[1][0], (bf16_t)acc[1][1], (bf16_t)acc[1][2], (bf16_t)acc[1][3]};
+                *reinterpret_cast<bf16x8_t*>(o) = v;
+            }
+        }
         if constexpr (STATS) {
             if (xin) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { st[k] += acc[k]; st[4 + k] += acc[k] * acc[k]; }
+                for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { st[h * 8 + k] += acc[h][k]; st[h * 8 + 4 + k] += acc[h][k] * acc[h][k]; }
             }
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { win[0][k] = win[1][k]; win[1][k] = win[2][k]; }
     }
     if constexpr (STATS) {
-        // thread t = ((pixel group * QB + local quad) << 2) + pixel lane; fixed summation order over the 4 * PG threads
-        // that hold the same quad
-        __shared__ float red[NT][8];
+        // thread t = ((pixel group * QB + local unit) << 2) + pixel lane; fixed summation order over the 4 * PG threads
+        // that hold the same unit
+        __shared__ float red[NT][NQ * 8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = st[k];
+        for (int k = 0; k < NQ * 8; ++k) red[threadIdx.x][k] = st[k];
         __syncthreads();
-        for (int o = threadIdx.x; o < QB * 8; o += NT) {
-            const int ql = o >> 3, k = o & 7;
+        for (int o = threadIdx.x; o < QB * NQ * 8; o += NT) {
+            const int ul = o / (NQ * 8), k = o % (NQ * 8);
             float t = 0.f;
             for (int g = 0; g < PG; ++g)
 #pragma unroll
-                for (int l = 0; l < 4; ++l) t += red[((g * QB + ql) << 2) + l][k];
-            const int ch = (blockIdx.y * QB + ql) * 4 + (k & 3);
-            stats[((size_t)blockIdx.x * C + ch) * 2 + (k >> 2)] = t;
+                for (int l = 0; l < 4; ++l) t += red[((g * QB + ul) << 2) + l][k];
+            const int ch = ((blockIdx.y * QB + ul) * NQ + (k >> 3)) * 4 + (k & 3);
+            stats[((size_t)blockIdx.x * C + ch) * 2 + ((k >> 2) & 1)] = t;
         }
     }
 }
 
-// geometry the matrix-core kernel covers: quads per workgroup divide 64, or 64 divides the quad count
+// geometry the matrix-core kernel covers: lane units (one quad, or two where 8 divides the channel count) per workgroup
+// divide 64, or 64 divides the unit count
+static int gconv_nq(int c) { return c % 8 == 0 ? 2 : 1; }
 static bool mfma_gconv_ok(int c, int cpg) {
-    const int Q = c / 4;
-    return cpg == 4 && (Q >= 64 ? Q % 64 == 0 : 64 % Q == 0);
+    if (cpg != 4 || c % 4) return false;
+    const int U = c / (4 * gconv_nq(c));
+    return U >= 64 ? U % 64 == 0 : 64 % U == 0;
 }
 
-struct GconvPlan { int Q, QB, xstrips, ystrips, RS; };
+struct GconvPlan { int NQ, U, QB, xstrips, ystrips, RS; };
 GconvPlan gconv_mfma_plan(int n, int h, int w_, int c) {
     GconvPlan p;
-    p.Q = c / 4;
-    p.QB = p.Q < 64 ? p.Q : 64;
+    p.NQ = gconv_nq(c);
+    p.U = c / (4 * p.NQ);
+    p.QB = p.U < 64 ? p.U : 64;
     const int PG = 64 / p.QB;
     p.xstrips = ur_cdiv(w_, 4 * PG);
     p.RS = 32;
-    while (p.RS > 4 && (long long)n * ur_cdiv(h, p.RS) * p.xstrips * (p.Q / p.QB) < 2048) p.RS >>= 1;
+    while (p.RS > 4 && (long long)n * ur_cdiv(h, p.RS) * p.xstrips * (p.U / p.QB) < 2048) p.RS >>= 1;
     p.ystrips = ur_cdiv(h, p.RS);
     return p;
 }
@@ -252,13 +290,13 @@ template <bool DGRAD>
 void launch_gconv_mfma(const bf16_t* in, const float* w, bf16_t* out, int n, int h, int w_, int c, hipStream_t st,
                        float* stats = nullptr) {
     const GconvPlan p = gconv_mfma_plan(n, h, w_, c);
-    const dim3 grid((unsigned)(n * p.ystrips * p.xstrips), p.Q / p.QB);
-    if (stats)
-        hipLaunchKernelGGL((gconv3x3_mfma_kernel<DGRAD, true>), grid, dim3(NT), 0, st, in, w, out, h, w_, c, p.QB, p.RS, p.xstrips,
-                           p.ystrips, stats);
-    else
-        hipLaunchKernelGGL((gconv3x3_mfma_kernel<DGRAD, false>), grid, dim3(NT), 0, st, in, w, out, h, w_, c, p.QB, p.RS, p.xstrips,
-                           p.ystrips, stats);
+    const dim3 grid((unsigned)(n * p.ystrips * p.xstrips), p.U / p.QB);
+#define GC_LAUNCH(ST, NQ_)                                                                                                  \
+    hipLaunchKernelGGL((gconv3x3_mfma_kernel<DGRAD, ST, NQ_>), grid, dim3(NT), 0, st, in, w, out, h, w_, c, p.QB, p.RS, p.xstrips, \
+                       p.ystrips, stats)
+    if (p.NQ == 2) { if (stats) GC_LAUNCH(true, 2); else GC_LAUNCH(false, 2); }
+    else { if (stats) GC_LAUNCH(true, 1); else GC_LAUNCH(false, 1); }
+#undef GC_LAUNCH
 }
 
 bool gconv_mfma_used(int dtype, int n, int h, int w_, int c, int cpg) {
@@ -408,7 +446,9 @@ int check_args(const void* a, const void* b, const void* c, int dtype, int n, in
     UR_REQUIRE(cpg == 1 || cpg == 4, "gconv3x3: channels per group must be 1 or 4 (got %d)", cpg);
     UR_REQUIRE(ch % 4 == 0, "gconv3x3: channel count %d is not a multiple of 4", ch);
     const int es = dtype == UR_BF16 ? 2 : 4;
-    UR_REQUIRE(((uintptr_t)a % (4 * es)) == 0 && ((uintptr_t)c % (4 * es)) == 0, "gconv3x3: misaligned tensor");
+    // 4-element accesses; 8-element (16-byte) ones in the bf16 matrix-core kernel where 8 divides the channel count
+    const int al = (dtype == UR_BF16 && cpg == 4 && ch % 8 == 0) ? 8 * es : 4 * es;
+    UR_REQUIRE(((uintptr_t)a % al) == 0 && ((uintptr_t)c % al) == 0, "gconv3x3: tensors must be %d-byte aligned", al);
     return UR_OK;
 }
 
