@@ -228,6 +228,14 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
 int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int act, int dtype, long long rows, int c, int dz_ld,
                          float* partial, ur_stream_t s);
+/* Backward of MaxPool2d(2, 2) (S/C:103-107) whose input is a BatchNorm+ReLU output (the encoder stage's result, which also
+ * feeds the skip connection, S/C:268-276): ur_maxpool2x2_bwd (dz = scattered pooled gradient + optional addend of pitch
+ * add_ld) and ur_bn_act_bwd_reduce (mask rebuilt from bn_y) in one pass.  dz is stored as ur_maxpool2x2_bwd stores it and the
+ * partial rows (ur_bn_stats_rows(n*h*w, c) of them) equal bit for bit what ur_bn_act_bwd_reduce computes from that dz. */
+int ur_maxpool2x2_bwd_bnsums_supported(int dtype, int n, int h, int w, int c);
+int ur_maxpool2x2_bwd_bnsums(const void* dpool, const uint8_t* idx, void* dz, const void* addend, int add_ld, const void* bn_y,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta, float* partial,
+                             int dtype, int n, int h, int w, int c, ur_stream_t s);
 /* sums[c][2] = reduce(partial); dgamma = sums[.,1]; dbeta = sums[.,0]; `partial` is used as scratch */
 int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
                        ur_stream_t s);

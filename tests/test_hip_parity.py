@@ -1289,3 +1289,78 @@ def test_spin_entry_point_and_stream_probe(pkg):
     assert side.cuda_stream != s.cuda_stream
     if any(" 0.3" in line.split("/")[1] for line in ops.stream_probe_log[-8:]):     # a concurrent candidate was found
         assert ops._overlaps(s, side)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,with_skip", [((2, 64, 64, 96), True), ((1, 16, 37, 51), True), ((3, 8, 20, 36), False),
+                                             ((2, 2048, 6, 10), True)])
+def test_maxpool_backward_with_bn_sums_matches_the_two_passes_bit_exactly(pkg, shape, with_skip):
+    """ur_maxpool2x2_bwd_bnsums = ur_maxpool2x2_bwd (scatter + skip-connection addend from a channel window) followed by
+    ur_bn_act_bwd_reduce on the stored gradient, in one pass: same dz, same partial rows, bit for bit; odd sizes (the
+    last row / column has no pooled gradient), a wide channel count and the form without an addend."""
+    lib = pkg._lib
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(17)
+    bf = torch.bfloat16
+    y = torch.randn(n, h, w, c, generator=g).to(DEV).to(bf)
+    x = torch.randn(n, h, w, c, generator=g).to(DEV).to(bf)
+    pooled = torch.empty(n, h // 2, w // 2, c, device=DEV, dtype=bf)
+    idx = torch.empty(n, h // 2, w // 2, c, device=DEV, dtype=torch.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.call("ur_maxpool2x2_fwd", x.data_ptr(), pooled.data_ptr(), idx.data_ptr(), lib.UR_BF16, n, h, w, c, c, st)
+    dpool = torch.randn(n, h // 2, w // 2, c, generator=g).to(DEV).to(bf)
+    add_ld = c + 16
+    wide = torch.randn(n, h, w, add_ld, generator=g).to(DEV).to(bf)          # the skip gradient: a window of a wider tensor
+    addend = wide.data_ptr() if with_skip else None
+    mean = torch.randn(c, generator=g).to(DEV) * 0.1
+    invstd = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(c, generator=g) * 0.3).to(DEV)
+    rows = n * h * w
+    nparts = lib.query("ur_bn_stats_rows", rows, c)
+    dz_a, dz_b = torch.empty_like(y), torch.empty_like(y)
+    pa = torch.zeros(nparts, c, 2, device=DEV)
+    pb = torch.ones(nparts, c, 2, device=DEV)
+    lib.call("ur_maxpool2x2_bwd", dpool.data_ptr(), idx.data_ptr(), dz_a.data_ptr(), addend, add_ld if with_skip else 0,
+             lib.UR_BF16, n, h, w, c, st)
+    lib.call("ur_bn_act_bwd_reduce", dz_a.data_ptr(), y.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+             beta.data_ptr(), lib.ACT_RELU, lib.UR_BF16, rows, c, c, pa.data_ptr(), st)
+    assert lib.query("ur_maxpool2x2_bwd_bnsums_supported", lib.UR_BF16, n, h, w, c)
+    lib.call("ur_maxpool2x2_bwd_bnsums", dpool.data_ptr(), idx.data_ptr(), dz_b.data_ptr(), addend, add_ld if with_skip else 0,
+             y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), pb.data_ptr(), lib.UR_BF16,
+             n, h, w, c, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dz_a, dz_b)
+    assert torch.equal(pa, pb)
+    assert pa.abs().sum().item() > 0
+
+
+@pytest.mark.gpu
+def test_pool_bn_sums_fusion_leaves_the_training_step_bit_identical(pkg):
+    """The encoder stages' BatchNorm backward takes its sums from the max-pool backward kernel: weights after Adam steps
+    equal those of the separate reduction pass bit for bit, and four reduction passes per step are gone."""
+    M, train, ops = pkg.modules.U_ResNet, pkg.train, pkg.ops
+
+    def run(fused):
+        old, ops.fuse_pool_bn_sums = ops.fuse_pool_bn_sums, fused
+        ops.kernel_timings, ops.kernel_timing_tags = [], {"hbm:bn_bwd_reduce"}
+        try:
+            torch.manual_seed(0)
+            m = M.UResNetNewEUCB(19, 3, 8).set_compute_dtype(torch.bfloat16).to(DEV).train()
+            opt = train.Adam(m.parameters(), lr=1e-3)
+            g = torch.Generator().manual_seed(7)
+            losses = []
+            for _ in range(3):
+                x = torch.randn(2, 3, 64, 96, generator=g).to(DEV)
+                y = torch.randint(0, 19, (2, 64, 96), generator=g).to(DEV)
+                losses.append(train.seg_train_step(m, opt, x, y)[0].item())
+            torch.cuda.synchronize()
+            return losses, [v.clone() for v in m.state_dict().values()], len(ops.kernel_timings)
+        finally:
+            ops.fuse_pool_bn_sums, ops.kernel_timings, ops.kernel_timing_tags = old, None, None
+
+    a, b = run(False), run(True)
+    assert a[0] == b[0]
+    for u, v in zip(a[1], b[1]):
+        assert torch.equal(u, v)
+    assert a[2] - b[2] == 3 * 4, (a[2], b[2])

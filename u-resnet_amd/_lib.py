@@ -87,6 +87,8 @@ SIGNATURES = {
     "ur_bn_eval_affine": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "ur_bn_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _i, _vp]),
     "ur_bn_act_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _i, _vp, _vp]),
+    "ur_maxpool2x2_bwd_bnsums_supported": (_i, [_i, _i, _i, _i, _i]),
+    "ur_maxpool2x2_bwd_bnsums": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ur_bn_bwd_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ur_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _ll, _i, _i, _vp]),
     "ur_maxpool2x2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

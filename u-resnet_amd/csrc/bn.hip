@@ -586,6 +586,81 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_bf16x8_kernel(
     }
 }
 
+// The same reduction for a BatchNorm(+ReLU) whose output went through a 2x2 max-pool (and, optionally, a skip
+// connection): the gradient dz of that output is the max-pool backward of the pooled gradient plus the skip
+// connection's gradient.  This kernel forms dz row by row exactly as the max-pool backward kernel does (pooled value where
+// the saved index selects this pixel, else zero; plus the addend), stores it, and feeds it to the sums -- same walk,
+// same summation order and same partial rows as bn_bwd_reduce_bf16x8_kernel on the stored dz, one pass over dz less.
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_pool_bf16x8_kernel(
+    const bf16_t* __restrict__ dpool, const uint8_t* __restrict__ idx, const bf16_t* __restrict__ addend, int add_ld,
+    bf16_t* __restrict__ dz, const bf16_t* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, unsigned rows, int H, int W, int C,
+    float* __restrict__ partial) {
+    constexpr int U = UR_BN_RED8_UNROLL;
+    __shared__ float red[NT * 16];
+    const int cq = C >> 3, slots = NT / cq;
+    const int tid = threadIdx.x, slot = tid / cq, cg = tid - slot * cq, col = cg * 8;
+    const int OH = H >> 1, OW = W >> 1;
+    Chan8 k;
+    k.load(mean, invstd, gamma, beta, col);
+    float s0[8], s1[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    struct Src { bf16x8_t g, a, y; uint2 sel; int me; bool pooled; };
+    auto fetch = [&](unsigned r) {
+        Src t;
+        const unsigned ix = r % (unsigned)W, q = r / (unsigned)W;
+        const unsigned iy = q % (unsigned)H, n = q / (unsigned)H;
+        const unsigned oy = iy >> 1, ox = ix >> 1;
+        t.me = (int)((iy & 1) * 2 + (ix & 1));
+        t.pooled = oy < (unsigned)OH && ox < (unsigned)OW;
+        const size_t op = (((size_t)n * OH + oy) * OW + ox) * C + col;
+        t.g = t.pooled ? ld_stream(dpool + op) : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        t.sel = t.pooled ? *reinterpret_cast<const uint2*>(idx + op) : make_uint2(0u, 0u);
+        if (addend) t.a = ld_stream(addend + (size_t)r * add_ld + col);
+        t.y = ld_stream(y + (size_t)r * C + col);
+        return t;
+    };
+    auto one = [&](const Src& t, unsigned r) {
+        bf16x8_t d8;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int sel = (int)(((v < 4 ? t.sel.x : t.sel.y) >> (8 * (v & 3))) & 0xffu);
+            float o = (t.pooled && sel == t.me) ? (float)t.g[v] : 0.f;
+            if (addend) o += (float)t.a[v];
+            d8[v] = (bf16_t)o;                                      // what the max-pool backward kernel stores
+        }
+        st_stream(dz + (size_t)r * C + col, d8);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const float xh = ((float)t.y[v] - k.m[v]) * k.is[v];
+            const float pre = xh * k.ga[v] + k.be[v];
+            const float gv = pre > 0.f ? (float)d8[v] : 0.f;
+            s0[v] += gv; s1[v] += gv * xh;
+        }
+    };
+    const unsigned step = gridDim.x * (unsigned)slots;
+    unsigned long long r = (unsigned long long)blockIdx.x * slots + slot;
+    if (slot >= slots) r = rows;                    // NT is not a multiple of C / 8: the surplus threads add nothing
+    for (; r + (unsigned long long)(U - 1) * step < rows; r += (unsigned long long)U * step) {
+        Src t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = fetch((unsigned)(r + (unsigned long long)u * step));
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(t[u], (unsigned)(r + (unsigned long long)u * step));
+    }
+    for (; r < rows; r += step) one(fetch((unsigned)r), (unsigned)r);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { red[(v * 2) * NT + tid] = s0[v]; red[(v * 2 + 1) * NT + tid] = s1[v]; }
+    __syncthreads();
+    for (int o = tid; o < cq * 16; o += NT) {
+        const int i = o / cq, g = o - i * cq;
+        float t = 0.f;
+        for (int sl = 0; sl < slots; ++sl) t += red[i * NT + sl * cq + g];
+        partial[((size_t)blockIdx.x * C + g * 8 + (i >> 1)) * 2 + (i & 1)] = t;
+    }
+}
+
 // Elementwise grid: enough workgroups to fill the chip several times over, each thread walking EW_UNROLL+ pieces.
 // The count is rounded down to a multiple of C / gcd(C, NT * 8) when possible, which makes the grid stride a
 // multiple of C (a thread then keeps its channels for the whole walk) for channel counts such as 80 too.
@@ -752,6 +827,30 @@ int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const flo
     });
 #undef UR_BN_RED
     return ur_check_launch("bn_act_bwd_reduce");
+}
+
+int ur_maxpool2x2_bwd_bnsums_supported(int dtype, int n, int h, int w, int c) {
+    return dtype == UR_BF16 && n > 0 && h > 1 && w > 1 && c > 0 && c % 8 == 0 && c / 8 <= NT &&
+           (long long)n * h * w < (1LL << 31);
+}
+
+int ur_maxpool2x2_bwd_bnsums(const void* dpool, const uint8_t* idx, void* dz, const void* addend, int add_ld, const void* bn_y,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta, float* partial,
+                             int dtype, int n, int h, int w, int c, ur_stream_t s) {
+    UR_REQUIRE(dpool && idx && dz && bn_y && mean && invstd && gamma && beta && partial, "maxpool2x2_bwd_bnsums: null pointer");
+    UR_REQUIRE(ur_maxpool2x2_bwd_bnsums_supported(dtype, n, h, w, c),
+               "maxpool2x2_bwd_bnsums: bf16, 8 | channels <= %d and fewer than 2^31 pixels only", NT * 8);
+    if (addend && add_ld == 0) add_ld = c;
+    UR_REQUIRE(!addend || (add_ld >= c && add_ld % 8 == 0), "maxpool2x2_bwd_bnsums: addend pitch %d (channels %d)", add_ld, c);
+    UR_REQUIRE(aligned16(dpool) && aligned16(dz) && aligned16(bn_y) && aligned16(addend) && ((uintptr_t)idx & 7) == 0 &&
+               aligned16(mean) && aligned16(invstd) && aligned16(gamma) && aligned16(beta),
+               "maxpool2x2_bwd_bnsums: tensors must be 16-byte aligned (index bytes 8)");
+    const long long rows = (long long)n * h * w;
+    const int grid = reduce_grid(rows, c, 4);                 // the grid of ur_bn_act_bwd_reduce: ur_bn_stats_rows(rows, c) partial rows
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_bf16x8_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)dpool, idx,
+                       (const bf16_t*)addend, add_ld, (bf16_t*)dz, (const bf16_t*)bn_y, mean, invstd, gamma, beta, (unsigned)rows,
+                       h, w, c, partial);
+    return ur_check_launch("maxpool2x2_bwd_bnsums");
 }
 
 int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,

@@ -551,7 +551,7 @@ class _Conv2d(Function):
                     add_ld = _channel_pitch(dalias)
                 add_ok = bool(add_ld and add_ld % 8 == 0)
                 rec = ctx.bn_rec
-                fuse = (fuse_bn_bwd_sums and rec is not None and (dalias is None or add_ok)
+                fuse = (fuse_bn_bwd_sums and rec is not None and not rec.window and (dalias is None or add_ok)
                         and tuple(rec.y.shape) == tuple(dx.shape) and rec.y.dtype == dx.dtype and _is_nhwc_dense(rec.y)
                         and (not rec.use_z or (_is_nhwc_dense(x) and x.data_ptr() % 16 == 0)))
                 # the 128-channel kernel has the plain, the addend and the mask-from-y BatchNorm epilogues
@@ -836,6 +836,7 @@ def gconv3x3(x, weight, want_stats=False):
 
 # ------------------------------------------------------------------------------ batch norm (+act, +residual)
 fuse_bn_bwd_sums = True     # False: BatchNorm backward always runs its own reduction pass (A/B comparisons)
+fuse_pool_bn_sums = os.environ.get("URESNET_POOL_BN_SUMS", "1") != "0"   # the max-pool backward kernel emits them too
 
 
 class _BNRecord:
@@ -847,10 +848,11 @@ class _BNRecord:
     (a second consumer of z would have made autograd add to it or replace it).  The record does not reference the output
     tensor itself (the tensor references the record): `use_z` tells the consumer that the ReLU mask must come from the
     stored output, which the consumer holds anyway as its saved input."""
-    __slots__ = ("y", "use_z", "gamma", "beta", "mean", "invstd", "partial", "dz_ptr", "dz_version")
+    __slots__ = ("y", "use_z", "gamma", "beta", "mean", "invstd", "partial", "dz_ptr", "dz_version", "window")
 
     def __init__(self):
         self.partial = None
+        self.window = False
 
 
 class _BNAct(Function):
@@ -891,9 +893,10 @@ class _BNAct(Function):
         ctx.act, ctx.eval, ctx.has_res = act, not training, residual is not None
         ctx.rec = None
         if (rec is not None and training and act == _lib.ACT_RELU and y.dtype == torch.bfloat16 and c % 8 == 0
-                and (out is None or via_dense) and y.data_ptr() % 16 == 0):
+                and y.data_ptr() % 16 == 0):
             rec.y, rec.use_z = y, residual is not None
             rec.gamma, rec.beta, rec.mean, rec.invstd = gamma, beta, mean, invstd
+            rec.window = not (out is None or via_dense)       # the result lives in a channel window of a wider tensor
             ctx.rec = rec
         if via_dense:
             if tuple(out[0].shape) != tuple(y.shape) or out[0].dtype != y.dtype or not _channel_pitch(out[0]):
@@ -1006,6 +1009,7 @@ class _MaxPool2x2Skip(Function):
                  _stream())
         ctx.save_for_backward(idx)
         ctx.shape = (n, c, h, w)
+        ctx.bn_rec = getattr(x, "_ur_bn", None)      # x is a BatchNorm+ReLU output: its backward sums can come from here
         ctx.set_materialize_grads(False)
         skip = torch.empty(0, dtype=x.dtype, device=x.device)
         skip.set_(x.untyped_storage(), x.storage_offset(), x.size(), x.stride())
@@ -1024,8 +1028,21 @@ class _MaxPool2x2Skip(Function):
             if not add_ld:
                 dskip, add_ld = _g(dskip), c
         dx = empty_nhwc(n, c, h, w, dy.dtype, dy.device)
-        with _Timed("hbm:maxpool_bwd", dx.numel() * dx.element_size() * (2 if dskip is not None else 1)
-                    + dy.numel() * (dy.element_size() + 1)):
+        tb = dx.numel() * dx.element_size()
+        rec = ctx.bn_rec
+        if (fuse_bn_bwd_sums and fuse_pool_bn_sums and rec is not None and not rec.use_z and rec.y.dtype == dy.dtype
+                and tuple(rec.y.shape) == (n, c, h, w) and _is_nhwc_dense(rec.y) and (dskip is None or add_ld % 8 == 0)
+                and (dskip is None or dskip.data_ptr() % 16 == 0)
+                and query("ur_maxpool2x2_bwd_bnsums_supported", _dt(dy), n, h, w, c)):
+            # dx is the gradient of a BatchNorm+ReLU output: the kernel that forms it also emits that BatchNorm's backward sums
+            partial = torch.empty((query("ur_bn_stats_rows", n * h * w, c), c, 2), dtype=torch.float32, device=dy.device)
+            with _Timed("hbm:maxpool_bwd_bn", tb * (3 if dskip is not None else 2) + dy.numel() * (dy.element_size() + 1)):
+                call("ur_maxpool2x2_bwd_bnsums", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _p(dskip), add_ld,
+                     rec.y.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.gamma.data_ptr(), rec.beta.data_ptr(),
+                     partial.data_ptr(), _dt(dy), n, h, w, c, _stream())
+            rec.partial, rec.dz_ptr, rec.dz_version = partial, dx.data_ptr(), dx._version
+            return dx
+        with _Timed("hbm:maxpool_bwd", tb * (2 if dskip is not None else 1) + dy.numel() * (dy.element_size() + 1)):
             call("ur_maxpool2x2_bwd", dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _p(dskip), add_ld, _dt(dy), n, h, w, c,
                  _stream())
         return dx
