@@ -1364,3 +1364,44 @@ def test_pool_bn_sums_fusion_leaves_the_training_step_bit_identical(pkg):
     for u, v in zip(a[1], b[1]):
         assert torch.equal(u, v)
     assert a[2] - b[2] == 3 * 4, (a[2], b[2])
+
+
+@pytest.mark.gpu
+def test_two_streams_with_gradient_accumulation_and_interleaved_evaluation(pkg):
+    """Patterns a training script may use around the two-stream forward: two backward passes accumulating into .grad
+    before one optimiser step (the second pass adds to gradients made on either stream), an evaluation forward under
+    no_grad between training steps, and torch's own optimiser consuming the gradients.  One and two streams agree bit
+    for bit."""
+    M, train, ops = pkg.modules.U_ResNet, pkg.train, pkg.ops
+
+    def run(two_streams):
+        old, ops.branch_streams = ops.branch_streams, two_streams
+        try:
+            torch.manual_seed(0)
+            m = M.UResNetNewEUCB(19, 3, 8).set_compute_dtype(torch.bfloat16).to(DEV).train()
+            opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+            g = torch.Generator().manual_seed(23)
+            seen = []
+            for it in range(3):
+                opt.zero_grad(set_to_none=True)
+                for _ in range(2):                                   # accumulate two micro-batches
+                    x = torch.randn(2, 3, 32, 64, generator=g).to(DEV)
+                    y = torch.randint(0, 19, (2, 32, 64), generator=g).to(DEV)
+                    loss = train.compute_loss(m(x), y)
+                    loss.backward()
+                    seen.append(loss.item())
+                opt.step()
+                ops.bump_weights_epoch()                             # torch's optimiser rewrote the parameters in place
+                m.eval()
+                with torch.no_grad():
+                    seen.append(m(torch.randn(1, 3, 64, 64, generator=g).to(DEV)).float().sum().item())
+                m.train()
+            torch.cuda.synchronize()
+            return seen, [v.clone() for v in m.state_dict().values()]
+        finally:
+            ops.branch_streams = old
+
+    one, two = run(False), run(True)
+    assert one[0] == two[0]
+    for a, b in zip(one[1], two[1]):
+        assert torch.equal(a, b)
