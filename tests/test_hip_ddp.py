@@ -46,6 +46,15 @@ l1, p1 = run(True)
 assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
 for a, b in zip(p0, p1):
     assert (a - b).norm().item() <= 1e-3 * a.norm().item() + 1e-7
+# the wrapper on one stream and on two (the gradients of a bucket then come from both streams and the collective waits
+# for per-stream delivery events): same bits; every gradient arrives in its bucket slice without a copy
+from uresnet_amd import ops
+ops.branch_streams = False
+l2, p2 = run(True)
+ops.branch_streams = True
+assert l1 == l2, (l1, l2)
+for a, b in zip(p1, p2):
+    assert torch.equal(a, b)
 dist.destroy_process_group()
 print("DDP_OK", l1)
 '''
