@@ -92,6 +92,15 @@ int ur_conv1x1_pw_wgrad_supported(const ur_conv_desc* d);
 size_t ur_conv1x1_pw_wgrad_workspace(const ur_conv_desc* d);
 int ur_conv1x1_pw_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
                         ur_stream_t s);
+/* The same two kernels for a 1x1 convolution whose input is BatchNorm(+ReLU) of a stored tensor (the segmentation head
+ * S/C:127-133 BN -> ReLU -> conv, EUCB* S/C:80-85): x is the BatchNorm's INPUT and in_aff = [2][cin] per-channel scale then
+ * shift (scale = gamma * invstd, shift = beta - mean * scale, as ur_bn_finalize_affine writes them); every 16-byte piece becomes
+ * bf16(max(x * scale + shift, 0)) (without max when relu == 0) on its way into the kernel's LDS rows, so the normalised
+ * tensor is never written or read. */
+int ur_conv1x1_pw_fwd_affine(const void* x, const float* in_aff, int in_relu, const float* w, int w_cout, int w_cin,
+                             const float* bias, void* y, const ur_conv_desc* d, ur_stream_t s);
+int ur_conv1x1_pw_wgrad_affine(const void* x, const float* x_aff, int x_relu, const void* dy, float* dw, void* workspace,
+                               size_t ws_bytes, const ur_conv_desc* d, ur_stream_t s);
 
 /* ---------------------------------------------------------------- 3x3 / stride 1 / pad 1, bf16: LDS-tiled kernel
  * Same contract as ur_conv2d_fwd / ur_conv2d_dgrad for the layers that carry ~94 % of the FLOPs
@@ -207,6 +216,11 @@ int ur_bn_stats(const void* y, int dtype, long long rows, int c, float* partial,
 int ur_bn_finalize(float* partial, int nparts, long long count, int c, float eps, float momentum,
                    float* mean, float* invstd, float* running_mean, float* running_var,
                    long long* num_batches_tracked, ur_stream_t s);
+/* ur_bn_finalize that also writes the normalisation as one multiply-add per element, aff = [2][c]: scale = gamma * invstd,
+ * then shift = beta - mean * scale (the constants ur_conv1x1_pw_fwd_affine / _wgrad_affine take) */
+int ur_bn_finalize_affine(float* partial, int nparts, long long count, int c, float eps, float momentum, float* mean,
+                          float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+                          const float* gamma, const float* beta, float* aff, ur_stream_t s);
 /* eval mode: mean = running_mean, invstd = rsqrt(running_var + eps) */
 int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int c, float eps, float* mean,
                        float* invstd, ur_stream_t s);

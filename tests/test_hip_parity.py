@@ -1405,3 +1405,50 @@ def test_two_streams_with_gradient_accumulation_and_interleaved_evaluation(pkg):
     assert one[0] == two[0]
     for a, b in zip(one[1], two[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,classes", [((2, 80, 256, 160), 19), ((1, 80, 301, 219), 19), ((2, 32, 200, 170), 16),
+                                           ((1, 48, 263, 251), 8)])
+def test_batchnorm_folded_into_the_1x1_convolution_matches_the_separate_passes(pkg, shape, classes):
+    """OutConv (S/C:127-133: BN -> ReLU -> 1x1 conv + bias) with the normalise pass folded into the streaming 1x1 kernels'
+    operand load (forward and backward-weight) against the same module with BatchNorm+ReLU as its own pass: output, input
+    gradient and every parameter gradient agree to bf16 rounding (the folded form is one multiply-add, the pass a
+    subtract-multiply-multiply-add: 1 element in ~100 rounds to the neighbouring bf16 value), running statistics bit for
+    bit; training and eval mode; ragged pixel counts and a class count that is not a multiple of 8; the normalise pass
+    really is gone (tensors of at least 2^16 pixels: below that the streaming backward-weight kernel is not used)."""
+    ops, B = pkg.ops, pkg.modules._blocks
+    n, c, h, w = shape
+    torch.manual_seed(3)
+    head = B.OutConv(c, classes).to(DEV)
+    with torch.no_grad():
+        head[0].weight.uniform_(0.5, 1.5); head[0].bias.uniform_(-0.3, 0.3)
+    x0 = torch.randn(n, c, h, w, device=DEV) * 2 + 0.3
+    g0 = torch.randn(n, classes, h, w, device=DEV)
+    state = {k: v.clone() for k, v in head.state_dict().items()}
+
+    def run(fused, train_mode):
+        head.load_state_dict(state)
+        head.train(train_mode)
+        old, ops.fuse_bn_into_conv1x1 = ops.fuse_bn_into_conv1x1, fused
+        ops.kernel_timings, ops.kernel_timing_tags = [], {"hbm:bn_fwd"}
+        try:
+            head.zero_grad(set_to_none=True)
+            x = ops.as_activation(x0, torch.bfloat16).detach().requires_grad_(True)
+            out = head(x)
+            out.backward(ops.as_activation(g0, torch.bfloat16))
+            passes = len(ops.kernel_timings)
+        finally:
+            ops.fuse_bn_into_conv1x1, ops.kernel_timings, ops.kernel_timing_tags = old, None, None
+        return (host(pkg, out), host(pkg, x.grad), {k: p.grad.clone() for k, p in head.named_parameters()},
+                {k: v.clone() for k, v in head.state_dict().items() if "running" in k or "num_batches" in k}, passes)
+
+    for train_mode in (True, False):
+        a, b = run(False, train_mode), run(True, train_mode)
+        assert a[4] == 1 and b[4] == 0
+        assert rel_l2(b[0], a[0]) < 4e-3
+        assert rel_l2(b[1], a[1]) < 6e-3
+        for k in a[2]:
+            assert rel_l2(b[2][k].cpu(), a[2][k].cpu()) < 6e-3, k
+        for k in a[3]:
+            assert torch.equal(a[3][k], b[3][k]), k

@@ -42,6 +42,8 @@ SIGNATURES = {
     "ur_conv1x1_pw_wgrad_supported": (_i, [_dp]),
     "ur_conv1x1_pw_wgrad_workspace": (_sz, [_dp]),
     "ur_conv1x1_pw_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
+    "ur_conv1x1_pw_fwd_affine": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _dp, _vp]),
+    "ur_conv1x1_pw_wgrad_affine": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _dp, _vp]),
     "ur_conv2d_wgrad_workspace": (_sz, [_dp]),
     "ur_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
     "ur_conv3x3_tile_supported": (_i, [_dp, _i]),
@@ -83,6 +85,7 @@ SIGNATURES = {
     "ur_bn_stats_rows": (_sz, [_ll, _i]),
     "ur_bn_stats": (_i, [_vp, _i, _ll, _i, _vp, _vp]),
     "ur_bn_finalize": (_i, [_vp, _i, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ur_bn_finalize_affine": (_i, [_vp, _i, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ur_bn_eval_prepare": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "ur_bn_eval_affine": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "ur_bn_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _i, _vp]),

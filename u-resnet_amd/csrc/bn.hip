@@ -184,7 +184,8 @@ int fold_partials(float* partial, int nparts, int C, hipStream_t st) {
 // out[c][k] = sum_p partial[p][c][k] in double; optional mean/invstd/running-stat epilogue
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, long long count, int C, float eps,
                                    float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt) {
+                                   float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ aff) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
@@ -206,6 +207,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (aff) {                                     // the normalisation folded to one multiply-add per element: [2][C]
+        const float k = gamma[c] * invstd[c];
+        aff[c] = k;
+        aff[C + c] = beta[c] - mean[c] * k;
+    }
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
     if (rvar) {
         double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
@@ -739,8 +745,20 @@ int ur_bn_finalize(float* partial, int nparts, long long count, int c, float eps
     nparts = fold_partials<2>(partial, nparts, c, (hipStream_t)s);
     if (int e = ur_check_launch("bn_fold_partials")) return e;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, count, c,
-                       eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
+                       eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr);
     return ur_check_launch("bn_finalize");
+}
+
+int ur_bn_finalize_affine(float* partial, int nparts, long long count, int c, float eps, float momentum, float* mean,
+                          float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+                          const float* gamma, const float* beta, float* aff, ur_stream_t s) {
+    UR_REQUIRE(partial && mean && invstd && gamma && beta && aff && nparts > 0 && count > 0 && c > 0, "bn_finalize_affine: bad arguments");
+    nparts = fold_partials<2>(partial, nparts, c, (hipStream_t)s);
+    if (int e = ur_check_launch("bn_fold_partials")) return e;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, count, c,
+                       eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta, aff);
+    return ur_check_launch("bn_finalize_affine");
 }
 
 int ur_bn_eval_prepare(const float* running_mean, const float* running_var, int c, float eps, float* mean,

@@ -33,7 +33,24 @@ struct PwParams {
     int wM, wK, sm, sk;
     int pitch_in, pitch_out;   // LDS row pitches in bytes
     int flat;                  // output rows are contiguous in memory and in LDS (out_ld == M): copy the chunk as bytes
+    const float* in_aff;       // AFF: [2][K] per-channel scale then shift applied to x on its way into LDS (a folded BatchNorm)
+    int in_relu;               // AFF: ReLU after the multiply-add
 };
+
+// x -> bf16(max(x * scale + shift, 0)) on 8 consecutive channels; cs = the channels' scales in LDS, their shifts K floats on
+__device__ __forceinline__ bf16x8_t pw_affine8(const bf16x8_t& v, const float* cs, int K, int relu) {
+    const float4 s0 = *reinterpret_cast<const float4*>(cs), s1 = *reinterpret_cast<const float4*>(cs + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(cs + K), h1 = *reinterpret_cast<const float4*>(cs + K + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float f = fmaf((float)v[e], sc[e], sh[e]);
+        if (relu) f = fmaxf(f, 0.f);
+        o[e] = (bf16_t)f;
+    }
+    return o;
+}
 
 // LDS row pitch for rows of `bytes`: the next odd multiple of 16 bytes above it
 int odd_pitch(int bytes) {
@@ -42,13 +59,20 @@ int odd_pitch(int bytes) {
     return q * 16;
 }
 
-template <int MT, int KS, bool BIAS>
+template <int MT, int KS, bool BIAS, bool AFF>
 __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 31, half = lane >> 5;
     unsigned char* lin = lds + (size_t)wave * 32 * (p.pitch_in + p.pitch_out);
     unsigned char* lout = lin + 32 * p.pitch_in;
+    // AFF: the input's per-channel constants sit behind the four waves' rows (the only workgroup barrier of the kernel)
+    const float* aff = reinterpret_cast<const float*>(lds + (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out));
+    if constexpr (AFF) {
+        float* a = const_cast<float*>(aff);
+        for (int i = threadIdx.x; i < 2 * p.K; i += NT) a[i] = p.in_aff[i];
+        __syncthreads();
+    }
 
     bf16x8_t wf[MT][KS];
 #pragma unroll
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
 
     // input pieces of a chunk: piece = i*64 + lane -> (pixel, 8-channel group); the same for every chunk
     const int gi = p.K >> 3, pieces_in = 32 * gi;
-    int ipix[KS], isrc[KS], ilds[KS];
+    int ipix[KS], isrc[KS], ilds[KS], ich[AFF ? KS : 1];
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
         const int id = i * 64 + lane;
@@ -86,6 +110,7 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
         ipix[i] = id < pieces_in ? pix : 32;                   // 32: no such piece
         isrc[i] = pix * p.in_ld + grp * 8;
         ilds[i] = pix * p.pitch_in + grp * 16;
+        if constexpr (AFF) ich[i] = grp * 8;
     }
     // output pieces: (pixel, group) of M/8 groups per pixel, or plain 16-byte pieces of the contiguous chunk
     constexpr int NO = 2 * MT;
@@ -121,7 +146,10 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     for (; ch < chunks; ch += wstep) {
 #pragma unroll
         for (int i = 0; i < KS; ++i)
-            if (ipix[i] < 32) *reinterpret_cast<bf16x8_t*>(lin + ilds[i]) = nxt[i];
+            if (ipix[i] < 32) {
+                if constexpr (AFF) *reinterpret_cast<bf16x8_t*>(lin + ilds[i]) = pw_affine8(nxt[i], aff + ich[i], p.K, p.in_relu);
+                else *reinterpret_cast<bf16x8_t*>(lin + ilds[i]) = nxt[i];
+            }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (ch + wstep < chunks) fetch(ch + wstep, nxt);
@@ -207,17 +235,17 @@ size_t lds_bytes(int K, int M, int out_ld) {
 
 // One resident round: as many workgroups as the device holds at this instantiation's register count, so that every
 // wave walks the same number of chunks and all finish together (no partially filled last round).
-template <int MT, int KS, bool BIAS>
+template <int MT, int KS, bool BIAS, bool AFF>
 void launch_one(long long chunks, hipStream_t st, const PwParams& p) {
-    const size_t lds = (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out);
+    const size_t lds = (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out) + (AFF ? (size_t)2 * p.K * sizeof(float) : 0);
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1x1_pw_kernel<MT, KS, BIAS>, NT, lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1x1_pw_kernel<MT, KS, BIAS, AFF>, NT, lds) != hipSuccess || per_cu < 1)
         per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
         cus = 256;
     const unsigned grid = (unsigned)ur_grid_1d(chunks, NT / 64, per_cu * cus);
-    hipLaunchKernelGGL((conv1x1_pw_kernel<MT, KS, BIAS>), dim3(grid), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((conv1x1_pw_kernel<MT, KS, BIAS, AFF>), dim3(grid), dim3(NT), lds, st, p);
 }
 
 template <int MT>
@@ -226,8 +254,10 @@ int launch_ks(int ks, long long chunks, hipStream_t st, const PwParams& p) {
 #define UR_PW_CASE(KS_)                                                 \
     case KS_:                                                           \
         if constexpr (MT * KS_ <= 6) {                                  \
-            if (p.bias) launch_one<MT, KS_, true>(chunks, st, p);       \
-            else launch_one<MT, KS_, false>(chunks, st, p);             \
+            if (p.in_aff && p.bias) launch_one<MT, KS_, true, true>(chunks, st, p);   \
+            else if (p.in_aff) launch_one<MT, KS_, false, true>(chunks, st, p);       \
+            else if (p.bias) launch_one<MT, KS_, true, false>(chunks, st, p);         \
+            else launch_one<MT, KS_, false, false>(chunks, st, p);                    \
         }                                                               \
         break;
         UR_PW_CASE(1) UR_PW_CASE(2) UR_PW_CASE(3) UR_PW_CASE(4) UR_PW_CASE(5)
@@ -247,7 +277,8 @@ int launch(PwParams p, hipStream_t st) {
     p.flat = !(p.M % 8 == 0 && p.out_ld % 8 == 0);
     p.pitch_in = odd_pitch(p.K * 2);
     p.pitch_out = p.flat ? p.M * 2 : odd_pitch(p.M * 2);
-    UR_REQUIRE(lds_bytes(p.K, p.M, p.out_ld) <= 64 * 1024, "conv1x1_pw: %d -> %d channels exceeds the LDS budget", p.K, p.M);
+    UR_REQUIRE(lds_bytes(p.K, p.M, p.out_ld) + 2 * p.K * sizeof(float) <= 64 * 1024, "conv1x1_pw: %d -> %d channels exceeds the LDS budget", p.K, p.M);
+    UR_REQUIRE(!p.in_aff || ((uintptr_t)p.in_aff & 3) == 0, "conv1x1_pw: misaligned input constants");
     if (p.P <= 0) return UR_OK;
     const long long chunks = (p.P + 31) / 32;
     switch (mt) {
@@ -281,6 +312,21 @@ int ur_conv1x1_pw_fwd(const void* x, const float* w, int w_cout, int w_cin, cons
     p.P = (long long)d->n * d->h * d->w;
     p.K = d->cin; p.M = d->cout; p.in_ld = d->in_ld ? d->in_ld : d->cin; p.out_ld = d->out_ld ? d->out_ld : d->cout;
     p.wM = w_cout; p.wK = w_cin; p.sm = w_cin; p.sk = 1;
+    return launch(p, (hipStream_t)s);
+}
+
+int ur_conv1x1_pw_fwd_affine(const void* x, const float* in_aff, int in_relu, const float* w, int w_cout, int w_cin,
+                             const float* bias, void* y, const ur_conv_desc* d, ur_stream_t s) {
+    UR_REQUIRE(x && in_aff && w && y && d, "conv1x1_pw_fwd_affine: null argument");
+    UR_REQUIRE(shape_ok(d), "conv1x1_pw_fwd_affine: not a bf16 1x1 stride-1 convolution");
+    UR_REQUIRE(w_cout <= d->cout && w_cin <= d->cin, "conv1x1_pw_fwd_affine: weight %dx%d exceeds the tensors' %dx%d channels",
+               w_cout, w_cin, d->cout, d->cin);
+    PwParams p{};
+    p.x = (const bf16_t*)x; p.w = w; p.bias = bias; p.y = (bf16_t*)y;
+    p.P = (long long)d->n * d->h * d->w;
+    p.K = d->cin; p.M = d->cout; p.in_ld = d->in_ld ? d->in_ld : d->cin; p.out_ld = d->out_ld ? d->out_ld : d->cout;
+    p.wM = w_cout; p.wK = w_cin; p.sm = w_cin; p.sk = 1;
+    p.in_aff = in_aff; p.in_relu = in_relu;
     return launch(p, (hipStream_t)s);
 }
 

@@ -26,7 +26,25 @@ struct PwWgParams {
     float* ws;           // [workgroups][16 MB][16 KB]
     long long P;
     int K, M, ld_x, ld_dy, pitch_x, pitch_y;
+    const float* x_aff;  // AFF: [2][K] per-channel scale then shift applied to x on its way into LDS (a folded BatchNorm)
+    int x_relu;          // AFF: ReLU after the multiply-add
+    int aff_off;         // AFF: byte offset of the constants inside the dynamic LDS (behind the staging rows and the sum buffer)
 };
+
+// x -> bf16(max(x * scale + shift, 0)) on 8 consecutive channels; cs = the channels' scales in LDS, their shifts K floats on
+__device__ __forceinline__ bf16x8_t pw_affine8(const bf16x8_t& v, const float* cs, int K, int relu) {
+    const float4 s0 = *reinterpret_cast<const float4*>(cs), s1 = *reinterpret_cast<const float4*>(cs + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(cs + K), h1 = *reinterpret_cast<const float4*>(cs + K + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float f = fmaf((float)v[e], sc[e], sh[e]);
+        if (relu) f = fmaxf(f, 0.f);
+        o[e] = (bf16_t)f;
+    }
+    return o;
+}
 
 int odd_pitch(int bytes) {
     int q = bytes / 16 + 1;
@@ -35,23 +53,30 @@ int odd_pitch(int bytes) {
 }
 
 // MB / KB = 16-channel blocks of dy / x that the instantiation covers (M <= 16 MB, K <= 16 KB; rows beyond M or K are zero)
-template <int MB, int KB>
+template <int MB, int KB, bool AFF>
 __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char* xt = lds + (size_t)wave * 32 * (p.pitch_x + p.pitch_y);
     unsigned char* yt = xt + 32 * p.pitch_x;
+    const float* aff = reinterpret_cast<const float*>(lds + p.aff_off);
+    if constexpr (AFF) {
+        float* a = const_cast<float*>(aff);
+        for (int i = threadIdx.x; i < 2 * p.K; i += NT) a[i] = p.x_aff[i];
+        __syncthreads();
+    }
 
     // pieces of a chunk: id = i * 64 + lane -> (pixel, 8-channel group); the same for every chunk
     const int gx = p.K >> 3, gy = p.M >> 3;
     constexpr int XL = KB, YL = MB;                       // loads per lane: 32 * gx <= 64 KB pieces, 32 * gy <= 64 MB
-    int xpix[XL], xsrc[XL], xlds[XL], ypix[YL], ysrc[YL], ylds[YL];
+    int xpix[XL], xsrc[XL], xlds[XL], ypix[YL], ysrc[YL], ylds[YL], xch[AFF ? XL : 1];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
         const int id = i * 64 + lane, pix = id / gx, grp = id - pix * gx;
         xpix[i] = id < 32 * gx ? pix : 1 << 20;
         xsrc[i] = pix * p.ld_x + grp * 8;
         xlds[i] = pix * p.pitch_x + grp * 16;
+        if constexpr (AFF) xch[i] = grp * 8;
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
@@ -103,7 +128,10 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < XL; ++i)
-            if (xpix[i] < 32) *reinterpret_cast<bf16x8_t*>(xt + xlds[i]) = xv[i];
+            if (xpix[i] < 32) {
+                if constexpr (AFF) *reinterpret_cast<bf16x8_t*>(xt + xlds[i]) = pw_affine8(xv[i], aff + xch[i], p.K, p.x_relu);
+                else *reinterpret_cast<bf16x8_t*>(xt + xlds[i]) = xv[i];
+            }
 #pragma unroll
         for (int i = 0; i < YL; ++i)
             if (ypix[i] < 32) *reinterpret_cast<bf16x8_t*>(yt + ylds[i]) = yv[i];
@@ -199,8 +227,11 @@ size_t ur_conv1x1_pw_wgrad_workspace(const ur_conv_desc* d) {
     return (size_t)PW_WG_GRID_MAX * c.mb * 16 * c.kb * 16 * sizeof(float);
 }
 
-int ur_conv1x1_pw_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
-                        ur_stream_t s) {
+}  // extern "C"
+
+namespace {
+int pw_wgrad_launch(const void* x, const float* x_aff, int x_relu, const void* dy, float* dw, void* workspace, size_t ws_bytes,
+                    const ur_conv_desc* d, ur_stream_t s) {
     Cfg c;
     UR_REQUIRE(shape_ok(d) && pick(d, c), "conv1x1_pw_wgrad: needs bf16, 1x1 stride 1, 8 | channels and pitches, cout <= 32, cin <= 96");
     UR_REQUIRE(x && dy && dw && workspace, "conv1x1_pw_wgrad: null pointer");
@@ -212,12 +243,21 @@ int ur_conv1x1_pw_wgrad(const void* x, const void* dy, float* dw, void* workspac
     p.K = d->cin; p.M = d->cout; p.ld_x = d->in_ld; p.ld_dy = d->out_ld;
     p.pitch_x = odd_pitch(c.kb * 32); p.pitch_y = odd_pitch(c.mb * 32);
     UR_REQUIRE(p.P * (p.ld_x > p.ld_dy ? p.ld_x : p.ld_dy) < (1LL << 31), "conv1x1_pw_wgrad: tensor exceeds 2^31 elements");
-    const size_t lds = lds_bytes(c);
+    size_t lds = lds_bytes(c);
+    if (x_aff) {                                   // the input's constants sit behind the staging rows / sum buffer
+        lds = (lds + 15) / 16 * 16;
+        p.x_aff = x_aff; p.x_relu = x_relu; p.aff_off = (int)lds;
+        lds += (size_t)2 * p.K * sizeof(float);
+    }
     const long long chunks = (p.P + 31) / 32;
     int grid = pw_wg_grid() < PW_WG_GRID_MAX ? pw_wg_grid() : PW_WG_GRID_MAX;
     if (chunks < (long long)grid * (NT / 64)) grid = (int)((chunks + NT / 64 - 1) / (NT / 64));
     hipStream_t st = (hipStream_t)s;
-#define UR_PW_WG(MB, KB) hipLaunchKernelGGL((pw_wgrad_kernel<MB, KB>), dim3(grid), dim3(NT), lds, st, p)
+#define UR_PW_WG(MB, KB)                                                                                  \
+    do {                                                                                                  \
+        if (x_aff) hipLaunchKernelGGL((pw_wgrad_kernel<MB, KB, true>), dim3(grid), dim3(NT), lds, st, p); \
+        else hipLaunchKernelGGL((pw_wgrad_kernel<MB, KB, false>), dim3(grid), dim3(NT), lds, st, p);      \
+    } while (0)
     if (c.mb == 1) UR_PW_WG(1, 2);
     else if (c.mb == 2 && c.kb == 2) UR_PW_WG(2, 2);
     else if (c.mb == 2 && c.kb == 5) UR_PW_WG(2, 5);
@@ -233,6 +273,20 @@ int ur_conv1x1_pw_wgrad(const void* x, const void* dy, float* dw, void* workspac
         hipLaunchKernelGGL(pw_wgrad_reduce_kernel<8>, dim3(ur_slab_grid(per, 8)), dim3(256), 0, st, p.ws, dw, rows, cols, d->cout,
                            d->cin, grid);
     return ur_check_launch("conv1x1_pw_wgrad_reduce");
+}
+}  // namespace
+
+extern "C" {
+
+int ur_conv1x1_pw_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
+                        ur_stream_t s) {
+    return pw_wgrad_launch(x, nullptr, 0, dy, dw, workspace, ws_bytes, d, s);
+}
+
+int ur_conv1x1_pw_wgrad_affine(const void* x, const float* x_aff, int x_relu, const void* dy, float* dw, void* workspace,
+                               size_t ws_bytes, const ur_conv_desc* d, ur_stream_t s) {
+    UR_REQUIRE(x_aff, "conv1x1_pw_wgrad_affine: null constants");
+    return pw_wgrad_launch(x, x_aff, x_relu, dy, dw, workspace, ws_bytes, d, s);
 }
 
 }  // extern "C"

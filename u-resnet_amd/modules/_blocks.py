@@ -181,7 +181,13 @@ class OutConv(hnn.Sequential):
         x = ops.as_activation(x, act_dtype(x))
         if has_hooks(*self):
             return super().forward(x)
-        return self[2](ops.bn_act(x, self[0], act=_lib.ACT_RELU))
+        conv = self[2]
+        if conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1):
+            # the normalise pass folded into the convolution's operand load (head of 80 channels at full resolution)
+            z = ops.bn_relu_conv1x1(x, self[0], conv)
+            if z is not None:
+                return z
+        return conv(ops.bn_act(x, self[0], act=_lib.ACT_RELU))
 
 
 class OutConvPlain(hnn.Sequential):

@@ -964,6 +964,132 @@ def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU, out=None):
     return z
 
 
+fuse_bn_into_conv1x1 = os.environ.get("URESNET_BN_PW", "1") != "0"   # False: BatchNorm+ReLU and the 1x1 convolution stay separate
+
+
+def _pw_descs(shape, cout, dtype, in_ld, out_ld):
+    """(forward descriptor, backward descriptor with the produced channels widened to a multiple of 8) of a 1x1 convolution."""
+    d = _desc(shape, cout, 1, 1, 1, 0, dtype)
+    d.in_ld, d.out_ld = in_ld, out_ld
+    db = _desc(shape, _pad8(cout), 1, 1, 1, 0, dtype)
+    db.in_ld = in_ld
+    return d, db
+
+
+class _BNReluConv1x1(Function):
+    """conv1x1(relu(BatchNorm(y))) (+bias) without the normalised tensor: the streaming 1x1 kernels apply the folded
+    BatchNorm (one multiply-add per element, then ReLU) to every piece of y on its way into their LDS rows -- forward
+    (ur_conv1x1_pw_fwd_affine) and backward-weight (ur_conv1x1_pw_wgrad_affine), the two kernels that read the activated
+    tensor.  Backward-data yields the gradient of the activated tensor, from which the usual two BatchNorm-backward passes
+    (mask rebuilt from y) produce dy.  Saves one pass over the tensor in forward (read y, write a) and the tensor itself."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, stats, running_mean, running_var, nbt, training, momentum, eps, weight, bias, out):
+        _require_gpu(y)
+        n, c, h, w = y.shape
+        rows, dev = n * h * w, y.device
+        cout = weight.shape[0]
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        aff = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        if training:
+            if stats is None:
+                stats = torch.empty((query("ur_bn_stats_rows", rows, c), c, 2), dtype=torch.float32, device=dev)
+                call("ur_bn_stats", y.data_ptr(), _dt(y), rows, c, stats.data_ptr(), _stream())
+            call("ur_bn_finalize_affine", stats.data_ptr(), stats.shape[0], rows, c, eps, momentum, mean.data_ptr(),
+                 invstd.data_ptr(), _p(running_mean), _p(running_var), _p(nbt), gamma.data_ptr(), beta.data_ptr(),
+                 aff.data_ptr(), _stream())
+        else:
+            call("ur_bn_eval_prepare", running_mean.data_ptr(), running_var.data_ptr(), c, eps, mean.data_ptr(),
+                 invstd.data_ptr(), _stream())
+            call("ur_bn_eval_affine", running_mean.data_ptr(), running_var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), c, eps,
+                 aff.data_ptr(), aff.data_ptr() + 4 * c, _stream())
+        if out is None:
+            z, out_ld = empty_nhwc(n, cout, h, w, y.dtype, dev), cout
+        else:
+            z, out_ld = out[0], _channel_pitch(out[0])
+            if tuple(z.shape) != (n, cout, h, w) or z.dtype != y.dtype or not out_ld:
+                raise RuntimeError("bn_relu_conv1x1: `out` must be a channel window with the output's shape and dtype")
+        d, dbk = _pw_descs(y.shape, cout, y.dtype, c, out_ld)
+        with _Timed("pw_fwd", _conv_flops(d), d):
+            call("ur_conv1x1_pw_fwd_affine", y.data_ptr(), aff.data_ptr(), 1, weight.data_ptr(), cout, c, _p(bias), z.data_ptr(),
+                 C.byref(d), _stream())
+        ctx.save_for_backward(y, weight, gamma, beta, mean, invstd, aff)
+        ctx.dbk, ctx.bias, ctx.eval = dbk, bias, not training
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, weight, gamma, beta, mean, invstd, aff = ctx.saved_tensors
+        d = ctx.dbk
+        n, c, h, w = y.shape
+        rows, dev = n * h * w, y.device
+        cout = weight.shape[0]
+        dz = _g(dz)
+        db = dw = None
+        if ctx.bias is not None and ctx.needs_input_grad[11]:
+            db = _colsum(dz.data_ptr(), d.dtype, rows, cout, cout, dev, ctx.bias)
+        if d.cout != cout:
+            dz = _pad_channels(dz, d.cout)
+        d.out_ld = d.cout
+        # gradient of the activated tensor a = relu(BatchNorm(y)), which exists in no buffer
+        da = empty_nhwc(n, c, h, w, y.dtype, dev)
+        with _Timed("pw_dgrad", _conv_flops(d), d):
+            call("ur_conv1x1_pw_dgrad", dz.data_ptr(), weight.data_ptr(), cout, c, da.data_ptr(), C.byref(d), _stream())
+        if ctx.needs_input_grad[10]:
+            dw = grad_buffer(weight, (d.cout, c, 1, 1))
+            ws = _workspace(query("ur_conv1x1_pw_wgrad_workspace", C.byref(d)), dev)
+            with _Timed("pw_wgrad", _conv_flops(d), d):
+                call("ur_conv1x1_pw_wgrad_affine", y.data_ptr(), aff.data_ptr(), 1, dz.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                     ws.numel(), C.byref(d), _stream())
+            if d.cout != cout:
+                dw = dw[:cout].contiguous()
+        tb = y.numel() * y.element_size()
+        partial = torch.empty((query("ur_bn_stats_rows", rows, c), c, 2), dtype=torch.float32, device=dev)
+        with _Timed("hbm:bn_bwd_reduce", tb * 2):
+            call("ur_bn_act_bwd_reduce", da.data_ptr(), y.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                 beta.data_ptr(), _lib.ACT_RELU, _dt(y), rows, c, c, partial.data_ptr(), _stream())
+        sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
+        dgamma, dbeta = grad_buffer(gamma), grad_buffer(beta)
+        call("ur_bn_bwd_finalize", partial.data_ptr(), partial.shape[0], c, sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+             _stream())
+        dy = torch.empty_like(y, memory_format=CL)
+        with _Timed("hbm:bn_bwd_apply", tb * 3):
+            call("ur_bn_act_bwd_apply", da.data_ptr(), y.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                 beta.data_ptr(), sums.data_ptr(), _lib.ACT_RELU, int(ctx.eval), dy.data_ptr(), None, _dt(y), rows, c, c,
+                 _stream())
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None, dw, db, None
+
+
+def bn_relu_conv1x1(y, bn, conv, stats=None, out=None):
+    """conv(relu(bn(y))) for a BatchNorm2d `bn` and a 1x1 stride-1 Conv2d `conv`, fused as _BNReluConv1x1 where the streaming
+    kernels cover the shape in all three directions; None otherwise (the caller then runs the two modules separately)."""
+    weight, bias = conv.weight, conv.bias
+    if (not (fuse_bn_into_conv1x1 and use_pw_kernel) or not y.is_cuda or y.dim() != 4 or y.dtype != torch.bfloat16
+            or not _is_nhwc_dense(y) or y.data_ptr() % 16 or tuple(weight.shape[2:]) != (1, 1) or weight.dtype != torch.float32
+            or not weight.is_contiguous() or weight.shape[1] != y.shape[1] or y.shape[1] % 8):
+        return None
+    training = bn.training or bn.running_mean is None
+    if training and bn.momentum is None:
+        return None
+    cout = weight.shape[0]
+    out_ld = cout if out is None else _channel_pitch(out)
+    if not out_ld:
+        return None
+    d, dbk = _pw_descs(y.shape, cout, y.dtype, y.shape[1], out_ld)
+    dbk.out_ld = dbk.cout
+    if not (query("ur_conv1x1_pw_supported", C.byref(d), 0) and query("ur_conv1x1_pw_supported", C.byref(dbk), 1)
+            and query("ur_conv1x1_pw_wgrad_supported", C.byref(dbk))):
+        return None
+    track = training and bn.track_running_stats and bn.running_mean is not None
+    return _BNReluConv1x1.apply(y, bn.weight, bn.bias, stats if training else None,
+                                bn.running_mean if (track or not training) else None,
+                                bn.running_var if (track or not training) else None,
+                                bn.num_batches_tracked if track else None,
+                                training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, weight, bias,
+                                None if out is None else (out,))
+
+
 # ------------------------------------------------------------------------------ spatial ops
 class _MaxPool2x2(Function):
     @staticmethod
