@@ -1452,3 +1452,47 @@ def test_batchnorm_folded_into_the_1x1_convolution_matches_the_separate_passes(p
             assert rel_l2(b[2][k].cpu(), a[2][k].cpu()) < 6e-3, k
         for k in a[3]:
             assert torch.equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("into_window", [False, True])
+def test_eucb2_with_the_last_batchnorm_folded_into_the_projection(pkg, into_window):
+    """EUCB* (S/C:59-87) at a size where the streaming 1x1 kernels serve all three directions: the last stage's BatchNorm+ReLU
+    folded into the 1x1 projection's operand load against the stage run pass by pass -- output (also written into a channel
+    window of a wider tensor, whose gradient window is then read in place), input gradient and parameter gradients agree
+    to bf16 rounding."""
+    ops, B = pkg.ops, pkg.modules._blocks
+    torch.manual_seed(5)
+    m = B.EUCB2(32, 16, scale_factor=2).to(DEV).train()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.3, 0.3)
+    x0 = torch.randn(2, 32, 100, 170, device=DEV)
+    g0 = torch.randn(2, 80, 200, 340, device=DEV)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def run(fused):
+        m.load_state_dict(state)
+        old, ops.fuse_bn_into_conv1x1 = ops.fuse_bn_into_conv1x1, fused
+        try:
+            m.zero_grad(set_to_none=True)
+            x = ops.as_activation(x0, torch.bfloat16).detach().requires_grad_(True)
+            g = ops.as_activation(g0, torch.bfloat16)
+            if into_window:
+                cat = ops.empty_nhwc(2, 80, 200, 340, torch.bfloat16, x.device)
+                out = m(x, out=ops.alias_window(cat, 64, 16))
+                assert out.data_ptr() == cat.data_ptr() + 64 * 2
+                out.backward(ops.alias_window(g, 64, 16))
+            else:
+                out = m(x)
+                out.backward(ops.dense(ops.alias_window(g, 64, 16)))
+            return host(pkg, ops.dense(out)), host(pkg, x.grad), {k: p.grad.clone() for k, p in m.named_parameters()}
+        finally:
+            ops.fuse_bn_into_conv1x1 = old
+
+    a, b = run(False), run(True)
+    assert rel_l2(b[0], a[0]) < 4e-3
+    assert rel_l2(b[1], a[1]) < 1e-2
+    for k in a[2]:
+        assert rel_l2(b[2][k].cpu(), a[2][k].cpu()) < 1e-2, k

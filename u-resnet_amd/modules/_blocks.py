@@ -47,6 +47,25 @@ def _cba(seq, x, i, out=None):
     return act(conv_bn_act(x, conv, bn, _lib.ACT_NONE))
 
 
+def _cba_conv1x1(seq, x, i, pw, out=None):
+    """seq[i] (conv), seq[i+1] (BN), seq[i+2] (ReLU) followed by the 1x1 convolution `pw`: the BatchNorm+ReLU pass is folded
+    into the 1x1 kernels' operand load where they cover the shape (ops.bn_relu_conv1x1), so the normalised tensor is not
+    materialised; None when that does not apply (the caller then runs the modules one by one)."""
+    conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
+    if (type(act) is not hnn.ReLU or not isinstance(pw, hnn.Conv2d) or pw.stride != (1, 1) or pw.padding != (0, 0)
+            or pw.groups != 1 or not ops.fuse_bn_into_conv1x1):
+        return None
+    n, _, h, w = x.shape
+    if n * h * w < 1 << 16 or x.dtype != torch.bfloat16:          # (below that the streaming backward-weight kernel is not used)
+        return None
+    y, stats = conv.raw(x, want_stats=bn.training)
+    z = ops.bn_relu_conv1x1(y, bn, pw, stats=stats, out=out)
+    if z is None:                                                # not covered after all: finish the stage the usual way
+        a = ops.bn_act(y, bn, stats=stats, act=_lib.ACT_RELU)
+        return pw.raw(a, out=out)[0] if out is not None else pw(a)
+    return z
+
+
 class EUCB(hnn.Module):
     """S/C:36-57: bilinear up -> depthwise 3x3 -> BN -> act -> shuffle(groups=C) -> 1x1 conv."""
 
@@ -103,13 +122,20 @@ class EUCB2(hnn.Module):
         """out: optional channel window for the result (honoured when no hooks are registered)."""
         x = ops.as_activation(x, act_dtype(x))
         hooked = has_hooks(self.pwc, *self.pwc, *[m for s in self._seqs() for m in (s, *s)])
-        for k, seq in enumerate(self._seqs()):
+        seqs = self._seqs()
+        for k, seq in enumerate(seqs):
             if k > 0:
                 x = channel_shuffle(x, self.in_channels)
             if hooked:
                 x = seq(x)
             elif k == 0:
                 x = _cba(seq, seq[0](x), 1)
+            elif k == len(seqs) - 1:
+                # the last stage feeds the 1x1 projection directly (S/C:84-86)
+                z = _cba_conv1x1(seq, x, 0, self.pwc[0], out)
+                if z is not None:
+                    return z
+                x = _cba(seq, x, 0)
             else:
                 x = _cba(seq, x, 0)
         if out is not None and not hooked:

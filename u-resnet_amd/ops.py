@@ -1025,13 +1025,20 @@ class _BNReluConv1x1(Function):
         n, c, h, w = y.shape
         rows, dev = n * h * w, y.device
         cout = weight.shape[0]
-        dz = _g(dz)
+        # a channel window of a wider gradient (the backward of the Feature Merge) is read in place
+        dz_ld = 0
+        if cout % 8 == 0 and dz.is_cuda and dz.dtype == y.dtype and not _is_nhwc_dense(dz) and dz.data_ptr() % 16 == 0:
+            dz_ld = _channel_pitch(dz)
+            if dz_ld % 8:
+                dz_ld = 0
+        if not dz_ld:
+            dz, dz_ld = _g(dz), cout
         db = dw = None
         if ctx.bias is not None and ctx.needs_input_grad[11]:
-            db = _colsum(dz.data_ptr(), d.dtype, rows, cout, cout, dev, ctx.bias)
+            db = _colsum(dz.data_ptr(), d.dtype, rows, cout, dz_ld, dev, ctx.bias)
         if d.cout != cout:
-            dz = _pad_channels(dz, d.cout)
-        d.out_ld = d.cout
+            dz, dz_ld = _pad_channels(dz, d.cout), d.cout
+        d.out_ld = dz_ld
         # gradient of the activated tensor a = relu(BatchNorm(y)), which exists in no buffer
         da = empty_nhwc(n, c, h, w, y.dtype, dev)
         with _Timed("pw_dgrad", _conv_flops(d), d):
