@@ -88,7 +88,12 @@ class EUCB(hnn.Module):
         if hooked:
             x = self.up_dwc(x)
         else:
-            x = _cba(self.up_dwc, self.up_dwc[0](x), 1)
+            u = self.up_dwc[0](x)
+            # (the shuffle between the stage and the projection is the identity: groups == channels, S/C:55)
+            z = _cba_conv1x1(self.up_dwc, u, 1, self.pwc[0], out)
+            if z is not None:
+                return z
+            x = _cba(self.up_dwc, u, 1)
         x = channel_shuffle(x, self.in_channels)
         if out is not None and not hooked:
             return self.pwc[0].raw(x, out=out)[0]
