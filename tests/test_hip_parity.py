@@ -245,6 +245,20 @@ def test_specialised_kernels_randomised_against_generic(pkg, monkeypatch):
     mod.main()                                   # exits non-zero on the first mismatch
 
 
+def test_fused_paths_randomised_against_separate_passes(pkg, monkeypatch):
+    """Random chains of DoubleConv / BasicBlock / Down at ragged sizes with the backward-pass fusions (BatchNorm sums from
+    the backward-data and max-pool epilogues, skip and residual gradients summed in kernel) on and off: same forward bits,
+    gradients equal to the order of the fp32 sums.  Then whole segmentation networks (S/C:223-409) at random sizes and
+    widths with every specialised path on against every one off (tools/stress_models.py)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_models.py")
+    spec = importlib.util.spec_from_file_location("stress_models", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["stress_models.py", "16", "5"])
+    mod.main()                                   # exits non-zero on the first mismatch
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 64, 8, 16, 32), (1, 128, 5, 7, 64), (2, 16, 4, 4, 8)])
 def test_conv_transpose2x2(pkg, shape, dtype):
