@@ -125,7 +125,7 @@ def main():
         # the two runs round intermediate tensors differently, ReLU masks flip and 41 BatchNorm layers amplify that: whole-model
         # gradients differ by 0.1 - 0.3 in the median between any two correct bf16 implementations (the sharp gradient check
         # is block_cases); an indexing error in the forward pass moves the logits by order one
-        if not finite or e_out > 3e-2 or abs(fast[1] - slow[1]) > 2e-2 * max(1.0, abs(slow[1])) or med > 0.4:
+        if not finite or e_out > 4e-2 or abs(fast[1] - slow[1]) > 2e-2 * max(1.0, abs(slow[1])) or med > 0.4:
             print("MISMATCH in case %d" % case)
             sys.exit(1)
     print("model stress OK: %d cases (seed %d), worst logits difference %.2e, worst median gradient difference %.2e" % (
