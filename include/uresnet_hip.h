@@ -170,6 +170,12 @@ int ur_wgrad3x3_tile_supported(const ur_conv_desc* d);
 size_t ur_wgrad3x3_tile_workspace(const ur_conv_desc* d);
 int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
                      const ur_conv_desc* d, ur_stream_t s);
+/* The same call for measurement harnesses: the library records `event_after_main` (a hipEvent_t, or NULL) on `s` between
+ * its two kernels, the matrix-core kernel that writes the partial slabs and the HBM-bound kernel that sums them, so that
+ * a caller bracketing the call with two events of its own gets each kernel's duration.  Only for layers where
+ * ur_wgrad3x3_tile_supported(d) == 1 (the 32 x 32-block kernel rejects a non-NULL event).  No counterpart in the reference. */
+int ur_wgrad3x3_tile_marked(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
+                            const ur_conv_desc* d, void* event_after_main, ur_stream_t s);
 
 /* ---------------------------------------------------------------- ConvTranspose2d(k=2, s=2) + bias
  * Replaces aten::conv_transpose2d of `Up.up` (S/C:113,117).  d describes the transposed

@@ -176,3 +176,38 @@ def test_wide_rejects_what_it_cannot_do(lib):
     # small problems stay with the tile kernel even where the shape is supported
     d = desc(lib, 1, 16, 32, 32, 128)
     assert lib.query("ur_conv3x3_wide_supported", C.byref(d), 0) == 1 and lib.query("ur_conv3x3_wide_preferred", C.byref(d), 0) == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 50, 64, 128), (1, 20, 70, 128, 64)])
+def test_backward_weight_with_a_marker_event_between_its_two_kernels(lib, shape):
+    """ur_wgrad3x3_tile_marked: the same two kernels as ur_wgrad3x3_tile (bit-identical gradient, checked against torch's
+    fp32 gradient of the same bf16 operands), with the caller's event recorded between them: start -> marker -> end are
+    ordered on the stream and both intervals are measurable.  The 32 x 32-block kernel refuses an event."""
+    n, h, w, cin, cout = shape
+    x, wt, dy = operands(shape, 21)
+    xd, dyd = nhwc(x).to(DEV), nhwc(dy).to(DEV)
+    d = desc(lib, n, h, w, cin, cout)
+    assert lib.query("ur_wgrad3x3_tile_supported", C.byref(d)) == 1
+    nws = lib.query("ur_wgrad3x3_tile_workspace", C.byref(d))
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    dw_a = torch.empty(cout, cin, 3, 3, device=DEV)
+    dw_b = torch.full_like(dw_a, 7.0)
+    lib.call("ur_wgrad3x3_tile", xd.data_ptr(), dyd.data_ptr(), dw_a.data_ptr(), ws.data_ptr(), nws, C.byref(d), stream())
+    st = torch.cuda.current_stream()
+    e0, mid, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    mid.record(st)
+    e0.record(st)
+    lib.call("ur_wgrad3x3_tile_marked", xd.data_ptr(), dyd.data_ptr(), dw_b.data_ptr(), ws.data_ptr(), nws, C.byref(d),
+             C.c_void_p(mid.cuda_event), stream())
+    e1.record(st)
+    torch.cuda.synchronize()
+    assert torch.equal(dw_a, dw_b)
+    assert e0.elapsed_time(mid) > 0 and mid.elapsed_time(e1) > 0
+    ref = torch.nn.grad.conv2d_weight(x.float(), wt.shape, dy.float(), padding=1)
+    assert rel_l2(dw_b.cpu(), ref) < 1e-4
+    d32 = desc(lib, 1, 16, 32, 32, 32)
+    if lib.query("ur_wgrad3x3_tile_supported", C.byref(d32)) == 2:
+        buf = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+        with pytest.raises(lib.UResNetHipError, match="takes no event"):
+            lib.call("ur_wgrad3x3_tile_marked", buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.numel(),
+                     C.byref(d32), C.c_void_p(mid.cuda_event), stream())

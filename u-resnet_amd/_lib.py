@@ -70,6 +70,7 @@ SIGNATURES = {
     "ur_wgrad3x3_tile_supported": (_i, [_dp]),
     "ur_wgrad3x3_tile_workspace": (_sz, [_dp]),
     "ur_wgrad3x3_tile": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
+    "ur_wgrad3x3_tile_marked": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp, _vp]),
     "ur_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_convT2x2_dgrad": (_i, [_vp, _vp, _vp, _dp, _vp]),
     "ur_convT2x2_wgrad_workspace": (_sz, [_dp]),

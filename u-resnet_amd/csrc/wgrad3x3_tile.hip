@@ -501,13 +501,20 @@ size_t ur_wgrad3x3_tile_workspace(const ur_conv_desc* d) {
 
 int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
                      ur_stream_t s) {
+    return ur_wgrad3x3_tile_marked(x, dy, dw, workspace, ws_bytes, d, nullptr, s);
+}
+
+int ur_wgrad3x3_tile_marked(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, const ur_conv_desc* d,
+                            void* event_after_main, ur_stream_t s) {
     UR_REQUIRE(supported(d), "wgrad3x3_tile: unsupported geometry (needs bf16, 3x3 s1 p1, 32 | cin, 32 | cout)");
     UR_REQUIRE(x && dy && dw && workspace, "wgrad3x3_tile: null pointer");
     UR_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "wgrad3x3_tile: tensors must be 16-byte aligned");
     UR_REQUIRE(ws_bytes >= ur_wgrad3x3_tile_workspace(d), "wgrad3x3_tile: workspace too small");
-    if (supported(d) == 2)
+    if (supported(d) == 2) {
+        UR_REQUIRE(!event_after_main, "wgrad3x3_tile_marked: the 32 x 32-block kernel takes no event");
         return wg32::run<false>((const bf16_t*)x, (const bf16_t*)dy, dw, (float*)workspace, d->n, d->h, d->w, d->cin, d->cout,
                                 d->in_ld, d->out_ld, (hipStream_t)s);
+    }
     Plan pl = make_plan(d);
     WgTileParams p{};
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.ws = (float*)workspace;
@@ -528,6 +535,10 @@ int ur_wgrad3x3_tile(const void* x, const void* dy, float* dw, void* workspace, 
     if (tile_rows() == 4) hipLaunchKernelGGL((wgrad3x3_tile_kernel<4, 1>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
     else hipLaunchKernelGGL((wgrad3x3_tile_kernel<2, 2>), dim3(pl.pairs * pl.nsplit), dim3(NTHREADS), 0, (hipStream_t)s, p);
     if (int e = ur_check_launch("wgrad3x3_tile")) return e;
+    if (event_after_main && hipEventRecord((hipEvent_t)event_after_main, (hipStream_t)s) != hipSuccess) {
+        ur_set_error("wgrad3x3_tile_marked: hipEventRecord failed");
+        return UR_ERR_LAUNCH;
+    }
     const long long per = (long long)d->cout * 9 * d->cin;
     if (ur_slab_lanes(pl.nsplit) == 32)
         hipLaunchKernelGGL(wgrad3x3_reduce_kernel<32>, dim3(ur_slab_grid(per, 32)), dim3(256), 0, (hipStream_t)s, p.ws, dw,

@@ -607,9 +607,24 @@ class _Conv2d(Function):
             if tile_w:
                 ws = _workspace(query("ur_wgrad3x3_tile_workspace", C.byref(d)), x.device)
                 # (supported == 2: the 32 x 32-block kernel for layers with 32 channels on a side)
-                with _Timed("tile_wgrad" if tile_w == 1 else "tile_wgrad32", _conv_flops(d), d):
-                    call("ur_wgrad3x3_tile", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
-                         C.byref(d), _stream())
+                if tile_w == 1 and kernel_timings is not None and (kernel_timing_tags is None or "tile_wgrad" in kernel_timing_tags):
+                    # timed: the library records `mid` between its matrix-core kernel and the slab reduction, so each of
+                    # the two gets its own duration (the FLOPs belong to the first, the second is a pass over the slabs)
+                    st = torch.cuda.current_stream()
+                    e0, mid, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    mid.record(st)                  # creates the handle; recorded again by the library
+                    e0.record(st)
+                    call("ur_wgrad3x3_tile_marked", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                         C.byref(d), C.c_void_p(mid.cuda_event), _stream())
+                    e1.record(st)
+                    shape = (d.n, d.h, d.w, d.cin, d.cout, d.kh, d.stride)
+                    kernel_timings.append(("tile_wgrad", _conv_flops(d), e0, mid, shape))
+                    kernel_timings.append(("hbm:wgrad3x3_reduce", float(query("ur_wgrad3x3_tile_workspace", C.byref(d)) + dw.numel() * 4),
+                                           mid, e1, None))
+                else:
+                    with _Timed("tile_wgrad" if tile_w == 1 else "tile_wgrad32", _conv_flops(d), d):
+                        call("ur_wgrad3x3_tile", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                             C.byref(d), _stream())
             elif use_pw_kernel and query("ur_conv1x1_pw_wgrad_supported", C.byref(d)):
                 ws = _workspace(query("ur_conv1x1_pw_wgrad_workspace", C.byref(d)), x.device)
                 with _Timed("pw_wgrad", _conv_flops(d), d):
