@@ -40,6 +40,7 @@ def _worker(rank, world, port, bucket_mb, ret):
         torch.manual_seed(100 + rank)            # different initial weights: the wrapper must broadcast rank 0's
         net = Net()
         ddp = DataParallel(net, bucket_mb=bucket_mb)
+        assert ddp.init_broadcasts == 1          # all parameters (one dtype, one device) travel in one flat buffer
         x, y = _data(world)
         xs, ys = shard_batch(x, rank, world), shard_batch(y, rank, world)
         for step in range(2):                    # second step checks that bucket state resets
@@ -184,6 +185,132 @@ def test_ranks_with_different_gradient_sets_raise_instead_of_hanging():
     ret = mp.Manager().dict()
     mp.spawn(_mismatch_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert "different sets of parameters" in ret[0] and "different sets of parameters" in ret[1]
+
+
+class TwoBranchOtherOrder(TwoBranch):
+    """Same parameters and function, evaluated branch after branch: backward delivers the gradients in another order."""
+
+    def forward(self, x):
+        b = F.relu(self.b2(F.relu(self.b1(x))))
+        a = F.relu(self.a2(F.relu(self.a1(x))))
+        return self.head(torch.cat([a, b], 1))
+
+
+def _disagree_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import uresnet_amd
+        from uresnet_amd.ddp import DataParallel, shard_batch
+        torch.manual_seed(7)
+        net = TwoBranch() if rank == 0 else TwoBranchOtherOrder()
+        ddp = DataParallel(net, bucket_mb=0.0008)
+        x, y = _data(world)
+        xs, ys = shard_batch(x, rank, world), shard_batch(y, rank, world)
+        for step in range(3):
+            net.zero_grad(set_to_none=True)
+            out = ddp(xs)
+            nll = F.cross_entropy(out, ys, ignore_index=255, reduction="sum")
+            valid = (ys != 255).sum().float()
+            count = ddp.count_hook(torch.stack([nll.detach(), valid, nll.detach() / valid]))
+            (nll / count[0]).backward()
+            ddp.finish()
+        ret[rank] = {"layout": ddp.bucket_layout(), "differs": ddp.arrival_order_differs_from_rank0,
+                     "grads": {k: p.grad.clone() for k, p in net.named_parameters()},
+                     "weights": {k: v.clone() for k, v in net.state_dict().items()}}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_whose_gradients_arrive_in_another_order_adopts_rank_0s_buckets():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_disagree_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0]["layout"] == ret[1]["layout"]              # same parameter at the same offset of the same bucket
+    assert ret[0]["differs"] is False and ret[1]["differs"] is True
+    net = TwoBranch()
+    net.load_state_dict(ret[0]["weights"])
+    x, y = _data(world)
+    F.cross_entropy(net(x), y, ignore_index=255).backward()
+    for k, p in net.named_parameters():                      # sums of matching gradients, on both ranks
+        assert torch.allclose(ret[0]["grads"][k], p.grad, rtol=1e-5, atol=1e-7), k
+        assert torch.equal(ret[0]["grads"][k], ret[1]["grads"][k]), k
+
+
+class _ScaleInto(torch.autograd.Function):
+    """y = x * w with the weight gradient written where ops.grad_buffer says, as the backward-weight kernels do."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x * w
+
+    @staticmethod
+    def backward(ctx, g):
+        from uresnet_amd import ops
+        x, w = ctx.saved_tensors
+        dw = ops.grad_buffer(w)
+        dw.copy_((g * x).sum().reshape(w.shape))
+        return g * w, dw
+
+
+class AppliedTwice(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = nn.Parameter(torch.tensor([1.5]))
+        self.v = nn.Parameter(torch.tensor([-0.5]))
+
+    def forward(self, x):
+        return _ScaleInto.apply(_ScaleInto.apply(x, self.w) + 1.0, self.w) * self.v
+
+
+def _twice_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import uresnet_amd
+        from uresnet_amd.ddp import DataParallel
+        net = AppliedTwice()
+        ddp = DataParallel(net)
+        x = torch.arange(1.0, 5.0) * (rank + 1)
+        for step in range(2):
+            net.zero_grad(set_to_none=True)
+            ddp(x).sum().backward()
+            ddp.finish()
+        ret[rank] = (net.w.grad.clone(), net.v.grad.clone(), ddp.in_place_elems, ddp.copied_elems)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_parameter_used_by_two_backward_nodes_gets_the_sum_of_both_gradients():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_twice_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    want_w, want_v = torch.zeros(1), torch.zeros(1)
+    for rank in range(world):
+        w, v = torch.tensor([1.5], requires_grad=True), torch.tensor([-0.5], requires_grad=True)
+        x = torch.arange(1.0, 5.0) * (rank + 1)
+        ((((x * w) + 1.0) * w) * v).sum().backward()
+        want_w += w.grad
+        want_v += v.grad
+    for rank in range(world):
+        assert torch.allclose(ret[rank][0], want_w, rtol=1e-6), (ret[rank][0], want_w)
+        assert torch.allclose(ret[rank][1], want_v, rtol=1e-6)
+
+
+def test_backend_and_device_pairings_that_cannot_work_are_refused():
+    from uresnet_amd.ddp import check_backend
+    check_backend("nccl", {"cuda"})
+    check_backend("gloo", {"cpu"})
+    check_backend("cpu:gloo,cuda:nccl", {"cpu", "cuda"})
+    with pytest.raises(RuntimeError, match="RCCL"):
+        check_backend("gloo", {"cuda"})                      # the pairing that hung in a two-process rehearsal on one GPU
+    with pytest.raises(RuntimeError, match="gloo"):
+        check_backend("nccl", {"cpu"})
+    with pytest.raises(RuntimeError, match="unsupported"):
+        check_backend("nccl", {"xpu"})
 
 
 def test_shard_batch_rejects_uneven_batches():

@@ -400,12 +400,13 @@ def grad_buffer(param, shape=None):
     """Tensor a backward-weight kernel writes the gradient of `param` into.  A data-parallel wrapper may register
     `param._ur_grad_slot`, a callable returning a fresh view of the parameter's slice of a gradient bucket: the kernel
     then fills the bucket directly and autograd adopts the view as `param.grad` without a copy.  Only when no gradient
-    is held yet (an accumulation `grad += dw` must not alias its own operand)."""
+    is held yet (an accumulation `grad += dw` must not alias its own operand); the callable returns None once the slice
+    has been handed out in this step (a parameter used by two backward nodes: the second kernel gets its own tensor)."""
     shape = tuple(param.shape) if shape is None else tuple(shape)
     slot = getattr(param, "_ur_grad_slot", None)
     if slot is not None and param.grad is None and shape == tuple(param.shape):
         t = slot()
-        if t.dtype == param.dtype and t.device == param.device and t.is_contiguous() and tuple(t.shape) == shape:
+        if t is not None and t.dtype == param.dtype and t.device == param.device and t.is_contiguous() and tuple(t.shape) == shape:
             return t
     return torch.empty(shape, dtype=param.dtype, device=param.device)
 
