@@ -11,9 +11,17 @@ JSON line and exits with the launcher's return code.
 
 One step = one pass of the hot path over one synthetic batch: NCHW fp32 images already resident in
 HBM -> UResNetNewEUCB(19, 3, 64) forward -> CE(ignore 255) -> backward -> [gradient all-reduce] ->
-Adam.  Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the implicit-GEMM
-convolution, forward + backward-data launches) timed live with events on its own stream;
-`cpu_baseline` is the oracle (plain PyTorch fp32 restatement of the reference) on the host cores.
+Adam.  Rank 0 prints ONE JSON line.  `roofline` describes the kernel family with the largest share of
+the step (kernels that do one job -- e.g. the two 3x3 forward / backward-data kernels with all their
+epilogue variants -- count as one family), timed live with events on the stream each launch runs on:
+the top-level numbers are those of the timed region's own streams, `isolated_one_stream` repeats them
+with every kernel alone on the chip, `matrix_pipe_utilisation_of_the_step` divides all convolution
+FLOPs by the wall time.  `cpu_baseline` is the oracle (plain PyTorch fp32 restatement of the reference)
+on the host cores.
+
+A rank that hangs does not sit until the caller's limit: with more than one rank every process arms a
+timer (URESNET_BENCH_DUMP_AFTER seconds, default 420) that prints every thread's stack and exits
+non-zero; the launcher then ends the other ranks and this script relays the return code.
 """
 import argparse
 import json
@@ -54,10 +62,11 @@ def parse():
                     help="with --gpus 1: still wrap the model in ddp.DataParallel over a one-rank RCCL group, so that the hooks, "
                          "the gradient buckets (filled in place by the backward-weight kernels) and the all-reduce launches run; "
                          "the difference to the plain line is the per-step cost of the data-parallel machinery on one GPU")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the whole training step (forward, loss, backward, Adam, weight repack) as one HIP graph and time "
-                         "replays; the per-kernel events of `roofline` cannot be recorded inside a graph, so they are taken from "
-                         "the same number of eager steps run right after the timed region (the line says so)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
+                    help="how the timed steps are launched: eagerly from Python, as one HIP graph replay per step (forward, loss, "
+                         "backward, [all-reduce,] Adam, weight repack captured once), or `auto`: capture the graph, time a few "
+                         "steps of both outside the timed region and use the faster (more than one rank: eager unless asked)")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="launch-path rehearsal without a GPU: the ranks rendezvous over gloo and push a small stand-in "
                          "torch.nn network through ddp.DataParallel; exercises spawning, bucketed all-reduce, the "
@@ -157,15 +166,15 @@ def rehearse_cpu(args):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed counter summary (profiles/*_pmc_traffic.json, made by
+    """(HBM bytes per launch, launches, source file) of `kernel` from the newest committed counter summary (profiles/*_pmc_traffic.json, made by
     tools/pmc_bench.sh + tools/pmc_traffic.py from two rocprofv3 --pmc passes over this same default workload).
     Hardware counters cannot be read from inside the timed process, so this is the one number not measured live."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
-        return None, None
+        return None, None, None
     rec = json.load(open(files[-1])).get("kernels", {}).get(kernel)
-    return (rec["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if rec else (None, None)
+    return (rec["hbm_bytes_per_launch"], rec["launches"], os.path.relpath(files[-1], ROOT)) if rec else (None, None, None)
 
 
 def cpu_baseline(height, width):
@@ -193,13 +202,17 @@ def cpu_baseline(height, width):
 
 def main():
     args = parse()
+    if args.graph:
+        args.launch = "graph"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # a hung rank prints every thread's stack and exits non-zero: always with more than one rank, on request with one
+    dump_after = os.environ.get("URESNET_BENCH_DUMP_AFTER", "420" if args.gpus > 1 else "")
+    if dump_after and int(dump_after) > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(int(dump_after), exit=True)
     if args.rehearse_cpu:
         return rehearse_cpu(args)
-    if os.environ.get("URESNET_BENCH_DUMP_AFTER"):          # a hung rank prints every thread's stack and exits
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["URESNET_BENCH_DUMP_AFTER"]), exit=True)
     import torch
     import torch.distributed as dist
     import uresnet_amd
@@ -248,10 +261,13 @@ def main():
     y[torch.rand(y.shape, generator=g) < 0.1] = 255
     y = y.to(dev)
 
-    def step():
+    def step_fn(model_, opt_, x_, y_):
         if ddp is None:
-            return train.seg_train_step(model, opt, x, y)
-        return train.seg_train_step(model, opt, x, y, count_hook=ddp.count_hook, grad_hook=ddp.finish)
+            return train.seg_train_step(model_, opt_, x_, y_)
+        return train.seg_train_step(model_, opt_, x_, y_, count_hook=ddp.count_hook, grad_hook=ddp.finish)
+
+    def step():
+        return step_fn(model, opt, x, y)
 
     def fence():
         torch.cuda.synchronize()
@@ -262,21 +278,34 @@ def main():
     for _ in range(args.warmup):
         loss, _ = step()
     fence()
-    graphed = None
-    if args.graph:
-        if ddp is not None:
-            raise SystemExit("--graph is a single-GPU option (the bucket hooks are host code)")
-        graphed = train.GraphedStep(train.seg_train_step, model, opt, x, y, warmup=1)
-        fence()
 
-    CONV_TAGS = {"tile_fwd", "tile_dgrad", "tile_dgrad_bn", "wide_fwd", "wide_dgrad", "wide_dgrad_bn", "tile_wgrad", "tile_wgrad32"}
+    FAMILIES = {          # kernels that do one job count as one family, whatever the number of kernels and epilogue variants
+        "conv3x3_forward_and_backward_data": {
+            "kernel": "conv3x3_tile_kernel<R, EPI> + conv3x3_wide_kernel<EPI>: the 3x3 s1 p1 forward and backward-data launches "
+                      "(one family: every layer goes to one of the two kernels, each with epilogue variants)",
+            "tags": ("tile_fwd", "tile_dgrad", "tile_dgrad_bn", "wide_fwd", "wide_dgrad", "wide_dgrad_bn"),
+            "pmc": ("conv3x3_tile_kernel", "conv3x3_tile_kernel (BatchNorm-backward sums in the epilogue)", "conv3x3_wide_kernel",
+                    "conv3x3_wide_kernel (BatchNorm-backward sums in the epilogue)")},
+        "conv3x3_backward_weight": {
+            "kernel": "wgrad3x3_strip_kernel: 3x3 s1 p1 backward-weight (its fp32 slab reduction, wgrad3x3_reduce_kernel, is an "
+                      "HBM-bound pass of its own: counted in this family's share of the step, not in its FLOP/s)",
+            "tags": ("tile_wgrad",), "time_only": ("hbm:wgrad3x3_reduce",), "pmc": ("wgrad3x3_strip_kernel",)},
+        "conv3x3_backward_weight_32_channels": {"kernel": "wgrad32_kernel: 3x3 backward-weight of the layers with 32 channels on a side",
+                                                "tags": ("tile_wgrad32",)},
+        "generic_forward_and_backward_data": {"kernel": "conv_igemm_kernel + conv1x1_pw_kernel: stem, 1x1, ConvT, skinny layers",
+                                              "tags": ("igemm_fwd", "igemm_dgrad", "pw_fwd", "pw_dgrad")},
+        "generic_backward_weight": {"kernel": "conv_wgrad_kernel (+ slab reduce) and pw_wgrad_kernel", "tags": ("wgrad", "pw_wgrad")},
+    }
+    CONV_TAGS = {t for f in FAMILIES.values() for t in f["tags"]}
+    TIMED_TAGS = set(FAMILIES["conv3x3_forward_and_backward_data"]["tags"]) | set(FAMILIES["conv3x3_backward_weight"]["tags"])
 
-    def timed_steps(fn, with_events, tags=CONV_TAGS):
-        if with_events and not args.no_kernel_timing:
+    def timed_steps(fn, tags, n=None):
+        n = args.steps if n is None else n
+        if tags is not None and not args.no_kernel_timing:
             ops.kernel_timings = []
-            ops.kernel_timing_tags = None if args.all_kernel_timing else tags
+            ops.kernel_timing_tags = None if (args.all_kernel_timing and tags is CONV_TAGS) else tags
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(n):
             loss, _ = fn()
         host = time.perf_counter() - t0              # launches enqueued; the GPU is still working
         fence()
@@ -284,26 +313,46 @@ def main():
         tm, ops.kernel_timings = ops.kernel_timings, None
         return loss, host, total, tm
 
-    if graphed is None:
-        # Two streams: the per-kernel numbers come from the one-stream pass below, so the timed region carries events only
-        # on the launches of the kernel that has been the dominant one (backward-weight, 29 of the 95 timed launches per
-        # step): 190 events per step cost 0.10-0.14 ms of a 28 ms step.
-        loss, host_elapsed, elapsed, timings = timed_steps(step, True, {"tile_wgrad"} if ops.branch_streams else CONV_TAGS)
+    # How a step is launched: eagerly (about 460 launches from Python) or as one HIP graph replay.  Which is faster depends on
+    # the box: one stream of graph nodes replays with fewer gaps than eager launches, but a graph with two branches is
+    # enqueued node by node by the runtime and its branches overlap less.  `auto` captures the graph, times a few steps
+    # of each outside the timed region and takes the faster one; with more than one rank the default is eager.
+    launch = args.launch
+    if launch == "auto" and ddp is not None:
+        launch = "eager"
+    graphed, calibration = None, None
+    if launch in ("auto", "graph"):
+        graphed = train.GraphedStep(step_fn, model, opt, x, y, warmup=1)
+        fence()
+    if launch == "auto":
+        n_cal = max(3, min(5, args.steps))
+        for fn in (step, lambda: graphed(x, y)):          # one untimed step of each after the capture
+            fn()
+        fence()
+        _, _, t_eager, _ = timed_steps(step, None, n_cal)
+        _, _, t_graph, _ = timed_steps(lambda: graphed(x, y), None, n_cal)
+        calibration = {"steps_each": n_cal, "eager_ms_per_step": round(t_eager / n_cal * 1e3, 3),
+                       "graph_replay_ms_per_step": round(t_graph / n_cal * 1e3, 3)}
+        launch = "graph" if t_graph < t_eager else "eager"
+    two_streams = bool(ops.branch_streams)
+
+    # ---- the timed region: exactly K steps between two fences -------------------------------------------------------------
+    # Eager: the launches of the two 3x3 families carry events on their own stream inside the timed region (about 190 events,
+    # 0.1 ms per step).  Graph replay: events cannot be recorded inside a graph; the same K steps are run eagerly, on the same
+    # streams, right after the timed region for the per-kernel numbers.
+    if launch == "eager":
+        loss, host_elapsed, elapsed, region_timings = timed_steps(step, TIMED_TAGS)
     else:
-        loss, host_elapsed, elapsed, _ = timed_steps(lambda: graphed(x, y), False)
-        keep, ops.branch_streams = ops.branch_streams, False    # kernel events: eager re-run on one stream, outside the timed region
-        _, _, eager_elapsed, timings = timed_steps(step, True)
-        ops.branch_streams = keep
+        loss, host_elapsed, elapsed, _ = timed_steps(lambda: graphed(x, y), None)
+        _, _, _, region_timings = timed_steps(step, TIMED_TAGS)
     final_loss = float(loss.item())
-    # With the two branches on two streams a kernel shares the chip with the other stream's kernels while it runs: the
-    # time between its two events is no longer its own.  The per-kernel numbers of `roofline` therefore come from the
-    # same steps run once more on ONE stream right after the timed region; what the events showed inside the timed
-    # region is kept next to them (`in_timed_region`), and `value` / `ms_per_step` are the timed region's alone.
-    concurrent_timings, isolated_elapsed = None, None
-    if ops.branch_streams and timings is not None and graphed is None:
-        concurrent_timings = timings
+    # With the two branches on two streams a kernel shares the chip with the other stream's kernels while it runs, so its
+    # event-to-event time (what a rocprofv3 trace of this command shows as well) is not the kernel's own.  The same K steps
+    # run once more on ONE stream give every kernel group alone on the chip.
+    isolated_timings, isolated_elapsed = None, None
+    if two_streams and region_timings is not None:
         ops.branch_streams = False
-        _, _, isolated_elapsed, timings = timed_steps(step, True)
+        _, _, isolated_elapsed, isolated_timings = timed_steps(step, CONV_TAGS)
         ops.branch_streams = True
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -320,120 +369,95 @@ def main():
 
     if rank == 0:
         peak = BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else FP32_MATRIX_PEAK_TFLOPS
+
         def fold(tm):
             kernels, shapes = {}, {}
             for tag, flops, e0, e1, shape in (tm or []):
-                sk = shapes.setdefault((tag, shape), [0, 0.0, 0.0])
-                sk[0] += 1; sk[1] += flops; sk[2] += e0.elapsed_time(e1) * 1e-3
-                k = kernels.setdefault(tag, [0, 0.0, 0.0])
-                k[0] += 1
-                k[1] += flops
-                k[2] += e0.elapsed_time(e1) * 1e-3
+                sec = e0.elapsed_time(e1) * 1e-3
+                for table, key in ((shapes, (tag, shape)), (kernels, tag)):
+                    k = table.setdefault(key, [0, 0.0, 0.0])
+                    k[0] += 1
+                    k[1] += flops
+                    k[2] += sec
             return kernels, shapes
-        kernels, shapes = fold(timings)
-        step_elapsed = elapsed                      # time shares refer to the pass the events were recorded in
-        if concurrent_timings is not None:
-            step_elapsed = isolated_elapsed
+
+        def family_stats(kernels, fam, wall):
+            own = [kernels[t] for t in fam["tags"] if t in kernels]
+            if not own:
+                return None
+            n, fl, sec = sum(k[0] for k in own), sum(k[1] for k in own), sum(k[2] for k in own)
+            extra = sum(kernels[t][2] for t in fam.get("time_only", ()) if t in kernels)
+            return {"achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4), "launches": n,
+                    "avg_launch_ms": round(sec / n * 1e3, 4), "flops_per_launch": fl / n,
+                    "time_share_of_step": round((sec + extra) / wall, 3)}
+
+        region_kernels, _ = fold(region_timings)
+        kernels, shapes = fold(isolated_timings if isolated_timings is not None else region_timings)
+        iso_wall = isolated_elapsed if isolated_timings is not None else elapsed
         roof = None
         if kernels:
-            groups = {
-                "conv3x3_tile_kernel<R, 0|1> (3x3 s1 p1 forward + plain backward-data launches)": ("tile_fwd", "tile_dgrad"),
-                "conv3x3_tile_kernel<R, 3..6> (backward-data launches that also read a BatchNorm's input and emit its "
-                "backward sums: the work of a separate HBM pass inside this kernel)": ("tile_dgrad_bn",),
-                "conv3x3_wide_kernel<0|1> (3x3 s1 p1 layers producing >= 128 channels: forward + plain backward-data launches)":
-                    ("wide_fwd", "wide_dgrad"),
-                "conv3x3_wide_kernel<3> (the same with the BatchNorm-backward sums in the epilogue)": ("wide_dgrad_bn",),
-                "conv_igemm_kernel (generic implicit GEMM: stem, 1x1, ConvT, skinny layers)": ("igemm_fwd", "igemm_dgrad", "pw_fwd", "pw_dgrad"),
-                "wgrad3x3_strip_kernel (3x3 s1 p1 backward-weight; its slab reduction is timed apart: wgrad3x3_reduce under other_kernels)": ("tile_wgrad",),
-                "wgrad32_kernel (3x3 backward-weight of the layers with 32 channels on a side)": ("tile_wgrad32",),
-                "conv_wgrad_kernel (generic backward-weight + slab reduce) and the streaming 1x1 backward-weight kernel": ("wgrad", "pw_wgrad"),
-            }
-            summary = {}
-            for name, tags in groups.items():
-                n = sum(kernels[t][0] for t in tags if t in kernels)
-                fl = sum(kernels[t][1] for t in tags if t in kernels)
-                sec = sum(kernels[t][2] for t in tags if t in kernels)
-                if n:
-                    summary[name] = {"achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4),
-                                     "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
-                                     "flops_per_launch": fl / n, "time_share_of_step": round(sec / step_elapsed, 3)}
-            dominant = max(summary, key=lambda k: summary[k]["time_share_of_step"])
-            dom = summary.pop(dominant)
+            iso = {name: family_stats(kernels, fam, iso_wall) for name, fam in FAMILIES.items()}
+            iso = {k: v for k, v in iso.items() if v}
+            dominant = max(iso, key=lambda k: iso[k]["time_share_of_step"])
+            fam = FAMILIES[dominant]
+            top = family_stats(region_kernels, fam, elapsed) or iso[dominant]
+            # HBM bytes per launch of the family's kernels from the newest committed counter passes (launch-weighted)
             traffic = source = None
-            default_workload = (B, H, W, args.dtype, world) == (6, 512, 1024, "bf16", 1)
-            if default_workload and dominant.startswith("conv3x3_"):
-                base = dominant.split("<")[0]
-                traffic, source = pmc_traffic(base + (" (BatchNorm-backward sums in the epilogue)"
-                                                      if ("3..6" in dominant or "<3>" in dominant) else ""))
-            elif default_workload and dominant.startswith("wgrad3x3_"):
-                traffic, source = pmc_traffic("wgrad3x3_strip_kernel")
-            # operands of the dominant group's launches: activations in and out once, the weight image once
+            if (B, H, W, args.dtype, world) == (6, 512, 1024, "bf16", 1) and fam.get("pmc"):
+                got = [pmc_traffic(k) for k in fam["pmc"]]
+                got = [(g[0], g[1], g[2]) for g in got if g[0] is not None]
+                if got:
+                    traffic = sum(b * n for b, n, _ in got) / sum(n for _, n, _ in got)
+                    source = got[0][2]
+            # operands of the family's launches: activations in and out once, the weight image once
             esz = 2 if dtype == torch.bfloat16 else 4
-            dom_bytes = [(n_ * h_ * w_ * (ci + co) + ci * co * k_ * k_) * esz
-                         for (tag, shp), (cnt, _, _) in shapes.items() if tag in groups[dominant] and shp
+            fam_bytes = [(n_ * h_ * w_ * (ci + co) + ci * co * k_ * k_) * esz
+                         for (tag, shp), (cnt, _, _) in shapes.items() if tag in fam["tags"] and shp
                          for (n_, h_, w_, ci, co, k_, _s) in [shp] for _ in range(cnt)]
-            roof = {"bound": "mfma", "kernel": dominant, "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": dom["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+            where = ("events inside the timed region (%s)" % ("two streams: a kernel shares the chip with the other stream's "
+                     "kernels while it runs, so these are what a rocprofv3 trace of this command shows, not the kernel alone: see "
+                     "isolated_one_stream" if two_streams else "one stream")) if launch == "eager" else \
+                    ("events over the same %d steps launched eagerly on the same streams right after the timed graph replays" % args.steps)
+            roof = {"bound": "mfma", "kernel": fam["kernel"], "family": dominant, "achieved": top["achieved"], "peak": peak,
+                    "unit": "TFLOP/s", "frac": top["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                     "traffic_source": source,
-                    "algorithmic_bytes_per_launch": (sum(dom_bytes) / len(dom_bytes)) if dom_bytes else None,
-                    "launches": dom["launches"],
-                    "avg_launch_ms": dom["avg_launch_ms"], "flops_per_launch": dom["flops_per_launch"],
-                    "time_share_of_step": dom["time_share_of_step"], "other_kernels": summary,
-                    "by_direction": {t: {"launches": kernels[t][0], "achieved": round(kernels[t][1] / kernels[t][2] / 1e12, 2),
-                                        "frac": round(kernels[t][1] / kernels[t][2] / 1e12 / peak, 4),
-                                        "avg_launch_ms": round(kernels[t][2] / kernels[t][0] * 1e3, 4)}
-                                    for t in groups[dominant] if t in kernels},
-                    "timing_region": (("the timed steps" if concurrent_timings is None else
-                                       "the same %d steps run on ONE stream right after the timed region (%.3f ms per step): in the "
-                                       "timed region the two branches of the network run on two streams and every kernel shares "
-                                       "the chip with the other stream's, so its event-to-event time is not its own"
-                                       % (args.steps, isolated_elapsed / args.steps * 1e3)) if graphed is None else
-                                      "the same %d steps run eagerly on one stream right after the timed graph replays "
-                                      "(%.3f ms per step)" % (args.steps, eager_elapsed / args.steps * 1e3))}
-            if concurrent_timings is not None:
-                ck, _ = fold(concurrent_timings)
-                n = sum(ck[t][0] for t in groups[dominant] if t in ck)
-                fl = sum(ck[t][1] for t in groups[dominant] if t in ck)
-                sec = sum(ck[t][2] for t in groups[dominant] if t in ck)
-                # the same launches run in both passes: their FLOPs are taken from the one-stream pass, which timed them all
-                cfl = sum(k[1] for t, k in kernels.items() if not t.startswith("hbm:"))
-                roof["in_timed_region"] = {
-                    "note": "event-to-event times of the same kernel while the other stream's kernels run beside it (these agree "
-                            "with a rocprofv3 kernel trace of this command; they overlap, so they do not add up to the step)",
-                    "timed_conv_kernels_flops_over_step_time": {
-                        "achieved": round(cfl / elapsed / 1e12, 2), "frac": round(cfl / elapsed / 1e12 / peak, 4), "unit": "TFLOP/s",
-                        "note": "FLOPs of the convolution launches timed in the one-stream pass, divided by the wall time of the "
-                                "timed region: the matrix-pipe utilisation of the whole step, all other kernels included"}}
-                if n:
-                    roof["in_timed_region"].update({"achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4),
-                                                    "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4)})
-            # the 3x3 forward / backward-data launches as one family (two kernels, each with epilogue variants): the numbers
-            # comparable with runs that had a single kernel for all of them
-            def family(tags):
-                fam = [kernels[t] for t in tags if t in kernels]
-                if not fam:
-                    return None
-                fl, sec, n = sum(k[1] for k in fam), sum(k[2] for k in fam), sum(k[0] for k in fam)
-                return {"achieved": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / peak, 4), "launches": n,
-                        "avg_launch_ms": round(sec / n * 1e3, 4), "time_share_of_step": round(sec / step_elapsed, 3)}
-            roof["conv3x3_forward_and_backward_data"] = {
-                "plain_launches": family(("tile_fwd", "tile_dgrad", "wide_fwd", "wide_dgrad")),
-                "launches_that_also_emit_batchnorm_backward_sums": family(("tile_dgrad_bn", "wide_dgrad_bn")),
-                "all": family(("tile_fwd", "tile_dgrad", "tile_dgrad_bn", "wide_fwd", "wide_dgrad", "wide_dgrad_bn"))}
+                    "algorithmic_bytes_per_launch": (sum(fam_bytes) / len(fam_bytes)) if fam_bytes else None,
+                    "launches": top["launches"], "avg_launch_ms": top["avg_launch_ms"], "flops_per_launch": top["flops_per_launch"],
+                    "time_share_of_step": top["time_share_of_step"], "timing_region": where,
+                    "dominant_by": "largest share of the step among the kernel families (one-stream pass)"}
+            if isolated_timings is not None:
+                roof["isolated_one_stream"] = dict(iso[dominant], note="the same %d steps run on ONE stream right after the timed "
+                                                   "region (%.3f ms per step): each kernel alone on the chip"
+                                                   % (args.steps, isolated_elapsed / args.steps * 1e3))
+            conv_flops = sum(k[1] for t_, k in kernels.items() if not t_.startswith("hbm:"))
+            roof["matrix_pipe_utilisation_of_the_step"] = {
+                "achieved": round(conv_flops / elapsed / 1e12, 2),
+                "frac": round(conv_flops / elapsed / 1e12 / peak, 4), "unit": "TFLOP/s",
+                "note": "FLOPs of every convolution launch of the K steps divided by the wall time of the timed region"}
+            roof["by_tag"] = {t_: {"launches": kernels[t_][0], "achieved": round(kernels[t_][1] / kernels[t_][2] / 1e12, 2),
+                                   "frac": round(kernels[t_][1] / kernels[t_][2] / 1e12 / peak, 4),
+                                   "avg_launch_ms": round(kernels[t_][2] / kernels[t_][0] * 1e3, 4)}
+                              for t_ in fam["tags"] if t_ in kernels}
+            roof["other_families"] = {FAMILIES[k]["kernel"]: v for k, v in iso.items() if k != dominant}
+            if region_kernels and isolated_timings is not None:
+                roof["other_families_in_timed_region"] = {
+                    FAMILIES[k]["kernel"]: family_stats(region_kernels, FAMILIES[k], elapsed)
+                    for k in FAMILIES if k != dominant and family_stats(region_kernels, FAMILIES[k], elapsed)}
+            hbm = {}
             for tag, (n, by, sec) in kernels.items():
                 if tag.startswith("hbm:") and n:
-                    summary[tag[4:] + " (HBM-bound, algorithmic bytes)"] = {
-                        "bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4), "launches": n,
-                        "avg_launch_ms": round(sec / n * 1e3, 4), "bytes_per_launch": by / n,
-                        "time_share_of_step": round(sec / step_elapsed, 3)}
-            conv_flops = sum(k[1] for t, k in kernels.items() if not t.startswith("hbm:"))
-            conv_secs = sum(k[2] for t, k in kernels.items() if not t.startswith("hbm:"))
+                    hbm[tag[4:]] = {"bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4), "launches": n,
+                                    "avg_launch_ms": round(sec / n * 1e3, 4), "bytes_per_launch": by / n,
+                                    "time_share_of_step": round(sec / iso_wall, 3)}
+            if hbm:
+                roof["hbm_bound_kernels"] = hbm
             if args.all_kernel_timing:
+                conv_secs = sum(k[2] for t_, k in kernels.items() if not t_.startswith("hbm:"))
                 roof["all_conv_mfma_util"] = round(conv_flops / conv_secs / 1e12 / peak, 4)
-                roof["all_conv_time_share_of_step"] = round(conv_secs / step_elapsed, 3)
+                roof["all_conv_time_share_of_step"] = round(conv_secs / iso_wall, 3)
             else:
-                roof["other_kernels_note"] = "run with --all-kernel-timing for the other kernel groups"
+                roof["other_kernels_note"] = "run with --all-kernel-timing for the BatchNorm, pooling and loss passes"
         if args.per_shape:
             for (tag, shape), (n, fl, sec) in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:args.per_shape_top]:
                 print("%-12s %-34s calls %4d  %8.3f ms/step  %7.1f %s" % (tag, shape, n, sec / args.steps * 1e3, fl / sec / 1e12,
@@ -461,7 +485,8 @@ def main():
                         "gradient_fraction_written_in_place_by_the_kernels":
                             round(ddp.in_place_elems / max(1, ddp.in_place_elems + ddp.copied_elems), 4)},
                        "branch_streams": ({"second_stream_probe": list(ops.stream_probe_log)} if ops.branch_streams else None),
-                       "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG"), "step_launch": "one HIP graph replay per step" if graphed is not None else "eager (about 460 launches per step)"},
+                       "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG"), "step_launch": "one HIP graph replay per step" if launch == "graph" else "eager (about 460 launches per step)",
+                       "step_launch_requested": args.launch, "step_launch_calibration": calibration},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
