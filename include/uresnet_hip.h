@@ -12,8 +12,10 @@
  *    buffer can be read or written in place.
  *  - dtype selects the activation storage type (UR_F32 or UR_BF16).  Parameters, their
  *    gradients, batch-norm statistics and loss values are always fp32.
- *  - The caller owns every buffer including workspaces; the library allocates nothing and
- *    keeps no mutable global state besides the thread-local error string.
+ *  - The caller owns every buffer including workspaces; the library allocates nothing.  Its only
+ *    mutable state is the thread-local error string and, for ur_ce_fwd_noalloc, one 8 KiB device
+ *    array per GPU inside the code object with a mutex-guarded table of its per-GPU addresses
+ *    (both private to the library).
  *  - All work is enqueued on the given stream (hipStream_t passed as void*); no call
  *    synchronises the device.
  *  - Return value: 0 on success, a negative UR_ERR_* code otherwise; ur_last_error()
@@ -349,11 +351,14 @@ int ur_ce_bwd(const void* logits, int dtype, const int64_t* target, long long ro
 /* ur_ce_fwd without a workspace argument and without any allocation.  No counterpart in the reference: it exists for
  * callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  The per-workgroup partial sums live in a device array inside the library (8 KiB per GPU, held
- * until the process ends; each GPU has its own copy, whose address is resolved on the first call made with that GPU
- * current).  Same kernels, same results as ur_ce_fwd bit for bit.  rows > ur_ce_fwd_noalloc_max_rows() (2^24) is
+ * until the process ends; each GPU has its own copy, whose address is resolved -- a runtime query that may load the
+ * code object -- by ur_ce_fwd_noalloc_prepare() or by the first call made with that GPU current: a caller that
+ * captures the call into a HIP graph calls ur_ce_fwd_noalloc_prepare() once per GPU BEFORE the capture begins; after
+ * that the call enqueues two kernels and nothing else).  Same kernels, same results as ur_ce_fwd bit for bit.  rows > ur_ce_fwd_noalloc_max_rows() (2^24) is
  * rejected with UR_ERR_INVALID.  All calls on one GPU share the array: calls that overlap on one GPU (different
  * streams or threads) race; calls on one stream, or otherwise ordered, are safe and need no clearing in between. */
 long long ur_ce_fwd_noalloc_max_rows(void);
+int ur_ce_fwd_noalloc_prepare(void);
 int ur_ce_fwd_noalloc(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
                       long long ignore_index, float* lse, float* out3, ur_stream_t s);
 /* BCEWithLogits, mean over all elements: out3 = {sum, count, mean} */

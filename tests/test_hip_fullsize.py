@@ -54,7 +54,9 @@ def test_config3_full_resolution_step_matches_oracle(pkg, oracle, dtype):
     loss = pkg.train.compute_loss(out, y.to(DEV))
     loss.backward()
     assert out.shape == (1, 19, 512, 1024)
-    assert rel_l2(host(pkg, out), ro.detach()) < (2e-4 if not bf16 else 4e-2)
+    # bf16: two correct implementations of the storage scheme are 2-2.7e-2 apart on logits (fp32 vs fp64 arithmetic in
+    # the emulating oracle, tests/test_oracle_golden.py::test_bf16_storage_noise_floor_...); measured here 1.6e-2
+    assert rel_l2(host(pkg, out), ro.detach()) < (2e-4 if not bf16 else 2.5e-2)
     assert abs(loss.item() - rl.item()) < (1e-5 if not bf16 else 2e-3) * abs(rl.item())
     # Gradients: with 5e5 pixels x 41 ReLU layers a handful of pre-activations sit within round-off of zero and
     # flip their mask (each flip shifts every upstream gradient, see tests/test_hip_parity.py); the reference's
@@ -249,7 +251,7 @@ def test_config4_full_resolution_1024x2048(pkg, oracle):
                 for k, v in stats_ref.items():
                     assert rel_l2(m.state_dict()[k].cpu(), v) < 1e-4, k
             else:
-                assert rel_l2(logits, ro_b) < 4e-2
+                assert rel_l2(logits, ro_b) < 3e-2      # the scheme's own noise floor is 2-2.7e-2 (see the oracle test)
                 assert abs(loss.item() - rl_b.item()) < 2e-3 * abs(rl_b.item())
             loss2, _ = pkg.train.seg_train_step(m, opt, xd, yd)
             assert torch.isfinite(loss2).item() and loss2.item() < loss.item()

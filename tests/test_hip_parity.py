@@ -840,6 +840,21 @@ def test_adam_keeps_a_step_count_per_parameter(pkg):
     assert rel_l2(b.detach().cpu(), rb.detach().cpu()) < 2e-6
     sd = opt.state_dict()['state']
     assert float(sd[0]['step']) == 4.0 and float(sd[1]['step']) == 2.0
+    # a parameter appended to the group afterwards: the counter pool grows by copy, the others keep their counts
+    c0 = torch.randn(50, device=DEV)
+    c, rc = c0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    opt.param_groups[0]['params'].append(c)
+    ropt.param_groups[0]['params'].append(rc)
+    for it in range(2):
+        for q, rq, n in ((a, ra, 300), (b, rb, 70), (c, rc, 50)):
+            g = torch.randn(n, device=DEV)
+            q.grad, rq.grad = g.clone(), g.clone()
+        opt.step()
+        ropt.step()
+    for q, rq in ((a, ra), (b, rb), (c, rc)):
+        assert rel_l2(q.detach().cpu(), rq.detach().cpu()) < 2e-6
+    sd = opt.state_dict()['state']
+    assert [float(sd[k]['step']) for k in (0, 1, 2)] == [6.0, 4.0, 2.0]
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 256, 512), (2, 64, 40, 72), (1, 32, 19, 45)])

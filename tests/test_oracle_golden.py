@@ -223,3 +223,40 @@ def test_temp_variant_matches_reference(oracle, name):
             for (k, p), n in zip([(k, p) for k, p in m.named_parameters() if p.grad is not None], rec["grad_norm"]):
                 assert abs(p.grad.double().norm().item() - n) <= 1e-3 * n + 1e-6, k
     assert np.allclose(losses, rec["losses"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("base,shape", [(8, (2, 3, 32, 64)), (32, (1, 3, 36, 52))])
+def test_bf16_storage_noise_floor_is_independent_of_any_kernel(oracle, base, shape):
+    """How far can two CORRECT implementations of the bf16-storage scheme be apart end to end?  The emulating oracle is
+    run twice on UResNetNewEUCB(19,3,base) (S/C:285-346) with identical weights, inputs and rounding points: once with
+    fp32 and once with fp64 arithmetic between the rounding points (a 1e-7 relative perturbation of every operator).
+    Rounding to bf16 turns such a perturbation d into about sqrt(d * 2^-8) per stored tensor, and 41 BatchNorm layers
+    amplify it: the logits end up 2-3e-2 apart, the parameter gradients 0.2 in the median.  That is the floor the GPU
+    end-to-end checks are measured against (smoke(), tests/test_hip_fullsize.py); an end-to-end 1e-2 is not attainable by
+    any implementation, which is why the 1e-2 bar is enforced per operator and per teacher-forced block instead."""
+    torch.manual_seed(0)
+    m32 = oracle.UResNetNewEUCB(19, 3, base)
+    state = {k: v.clone() for k, v in m32.state_dict().items()}
+    m64 = oracle.UResNetNewEUCB(19, 3, base)
+    m64.load_state_dict(state)
+    m64.double()
+    oracle.emulate_bf16_storage(m32)
+    oracle.emulate_bf16_storage(m64)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(*shape, generator=g)
+    y = torch.randint(0, 19, (shape[0],) + shape[2:], generator=g)
+    y[torch.rand(y.shape, generator=g) < 0.1] = 255
+    o32 = m32(x)
+    l32 = oracle.compute_loss(o32, y)
+    l32.backward()
+    o64 = m64(x.double())
+    l64 = oracle.compute_loss(o64, y)
+    l64.backward()
+    logits = rel_l2(o32.detach(), o64.detach().float())
+    grads = sorted(rel_l2(p.grad, q.grad.float()) for p, q in zip(m32.parameters(), m64.parameters())
+                   if p.grad is not None and q.grad.norm() > 0)
+    print("\nbf16 noise floor, base %d input %s: logits rel-L2 %.3e, loss %.6f vs %.6f, gradient rel-L2 median %.3e max %.3e"
+          % (base, shape, logits, l32.item(), l64.item(), grads[len(grads) // 2], grads[-1]))
+    assert 1e-2 < logits < 4e-2              # measured 2.7e-2 / 2.0e-2: above the per-operator bar, by construction of the scheme
+    assert abs(l32.item() - l64.item()) < 1e-3 * l64.item()
+    assert 5e-2 < grads[len(grads) // 2] < 0.5

@@ -70,3 +70,36 @@ def test_ce_fwd_noalloc_rejects_sizes_beyond_its_limit():
     rc = lib.ur_ce_fwd_noalloc(logits.data_ptr(), _lib.UR_BF16, target.data_ptr(), limit + 1, 19, 19, 255, lse.data_ptr(),
                                out3.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == -1 and b"exceed the limit" in lib.ur_last_error()
+
+
+def test_ce_fwd_noalloc_is_capturable_after_prepare():
+    """The entry point inside a HIP graph: the per-GPU address of the library's array is resolved by
+    ur_ce_fwd_noalloc_prepare() before the capture, the captured call enqueues kernels only, and every replay gives the
+    workspace version's bits (the second replay on new logits written into the same buffers)."""
+    from uresnet_amd import _lib
+    _lib.load()
+    _lib.call("ur_ce_fwd_noalloc_prepare")
+    rows, classes = 70001, 19
+    logits, target = _inputs(rows, classes, torch.bfloat16, 5)
+    lse = torch.zeros(rows, dtype=torch.float32, device=DEV)
+    out3 = torch.zeros(3, dtype=torch.float32, device=DEV)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            _lib.call("ur_ce_fwd_noalloc", logits.data_ptr(), _lib.UR_BF16, target.data_ptr(), rows, classes, classes, 255,
+                      lse.data_ptr(), out3.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    ws = torch.empty(max(int(_lib.query("ur_loss_workspace", rows)), 16), dtype=torch.uint8, device=DEV)
+    for seed in (6, 7):
+        new_logits, new_target = _inputs(rows, classes, torch.bfloat16, seed)
+        logits.copy_(new_logits)
+        target.copy_(new_target)
+        graph.replay()
+        lse_ref = torch.empty_like(lse)
+        out_ref = torch.empty_like(out3)
+        _lib.call("ur_ce_fwd", logits.data_ptr(), _lib.UR_BF16, target.data_ptr(), rows, classes, classes, 255,
+                  lse_ref.data_ptr(), out_ref.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(lse, lse_ref) and torch.equal(out3, out_ref), seed

@@ -117,6 +117,7 @@ SIGNATURES = {
     "ur_loss_workspace": (_sz, [_ll]),
     "ur_ce_fwd": (_i, [_vp, _i, _vp, _ll, _i, _i, _ll, _vp, _vp, _vp, _sz, _vp]),
     "ur_ce_fwd_noalloc_max_rows": (_ll, []),
+    "ur_ce_fwd_noalloc_prepare": (_i, []),
     "ur_ce_fwd_noalloc": (_i, [_vp, _i, _vp, _ll, _i, _i, _ll, _vp, _vp, _vp]),
     "ur_ce_bwd": (_i, [_vp, _i, _vp, _ll, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp]),
     "ur_bce_fwd": (_i, [_vp, _i, _vp, _ll, _vp, _vp, _sz, _vp]),

@@ -274,8 +274,8 @@ constexpr int CE_NOALLOC_MAX_BLOCKS = 1024;
 constexpr long long CE_NOALLOC_MAX_ROWS = 1LL << 24;       // 64 rows per thread of the largest grid
 constexpr int CE_MAX_DEVICES = 64;
 static __device__ __align__(256) float ce_scratch[CE_NOALLOC_MAX_BLOCKS * 2];
-float* ce_scratch_dev[CE_MAX_DEVICES];                      // device address of ce_scratch on GPU i (nullptr: not resolved yet)
-pthread_mutex_t ce_scratch_lock = PTHREAD_MUTEX_INITIALIZER;
+static float* ce_scratch_dev[CE_MAX_DEVICES];               // device address of ce_scratch on GPU i (nullptr: not resolved yet)
+static pthread_mutex_t ce_scratch_lock = PTHREAD_MUTEX_INITIALIZER;
 
 // Device address of the current GPU's ce_scratch, or nullptr with the error string set.
 float* ce_scratch_for_current_device() {
@@ -326,6 +326,8 @@ int ur_ce_fwd(const void* logits, int dtype, const int64_t* target, long long ro
 }
 
 long long ur_ce_fwd_noalloc_max_rows(void) { return CE_NOALLOC_MAX_ROWS; }
+
+int ur_ce_fwd_noalloc_prepare(void) { return ce_scratch_for_current_device() ? UR_OK : UR_ERR_INVALID; }
 
 int ur_ce_fwd_noalloc(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
                       long long ignore_index, float* lse, float* out3, ur_stream_t s) {

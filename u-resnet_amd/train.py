@@ -181,25 +181,46 @@ class Adam(_MultiTensorOptimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._step_pools = {}
+        self._step_pools = {}          # (group index, device) -> int32 pool of step counters
+        self._pool_index = {}          # (group index, device) -> {parameter: slot}
 
     def _step_slot(self, gi, p):
-        """0-dim int32 device view: the step counter of parameter p of group gi."""
-        group = self.param_groups[gi]
-        pool = self._step_pools.get(gi)
-        if pool is None or pool.numel() != len(group['params']) or pool.device != p.device:
+        """0-dim int32 device view: the step counter of parameter p of group gi.  One pool per (group, device); a pool
+        grows by copy when the group has gained parameters, so counters handed out earlier keep their values (their
+        old views stay valid for the kernel table, which is rebuilt from `state[p]['step']` at every step)."""
+        key = (gi, p.device)
+        pool = self._step_pools.get(key)
+        index = self._pool_index.setdefault(key, {})
+        if p not in index:
+            index[p] = len(index)
+        need = index[p] + 1
+        if pool is None or pool.numel() < need:
             if p.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("Adam: run at least one eager step before capturing")
-            pool = torch.zeros(len(group['params']), dtype=torch.int32, device=p.device)
-            self._step_pools[gi] = pool
-            self._pool_index = getattr(self, '_pool_index', {})
-            for i, q in enumerate(group['params']):
-                self._pool_index[q] = (gi, i)
-        return pool[self._pool_index[p][1]]
+            size = max(need, len(self.param_groups[gi]['params']))
+            grown = torch.zeros(size, dtype=torch.int32, device=p.device)
+            if pool is not None:
+                grown[:pool.numel()].copy_(pool)
+                for q, i in index.items():                  # counters already handed out move with their values
+                    st = self.state.get(q)
+                    if st and 'step' in st and i < pool.numel():
+                        st['step'] = grown[i]
+            pool = self._step_pools[key] = grown
+        return pool[index[p]]
 
     def state_dict(self):
         sd = super().state_dict()
-        sd['state'] = {k: {**v, 'step': torch.tensor(float(v['step']))} if 'step' in v else v for k, v in sd['state'].items()}
+        # one device read per pool instead of one per parameter
+        host = {key: pool.cpu() for key, pool in self._step_pools.items()}
+        slot = {q: (key, i) for key, index in self._pool_index.items() for q, i in index.items()}
+        order = [q for group in self.param_groups for q in group['params']]      # torch numbers the parameters this way
+
+        def step_of(k, v):
+            q = order[k]
+            if q in slot and slot[q][0] in host:
+                return float(host[slot[q][0]][slot[q][1]])
+            return float(v['step'])
+        sd['state'] = {k: ({**v, 'step': torch.tensor(step_of(k, v))} if 'step' in v else v) for k, v in sd['state'].items()}
         for g in sd['param_groups']:                 # torch.optim.Adam's remaining group keys, at their defaults
             for k, v in (('amsgrad', False), ('maximize', False), ('foreach', None), ('capturable', False),
                          ('differentiable', False), ('fused', None), ('decoupled_weight_decay', False)):
@@ -214,7 +235,7 @@ class Adam(_MultiTensorOptimizer):
         slim = {'state': state_dict['state'],
                 'param_groups': [{k: v for k, v in g.items() if k in keep} for g in state_dict['param_groups']]}
         super().load_state_dict(slim)
-        self._step_pools = {}
+        self._step_pools, self._pool_index = {}, {}
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
                 st = self.state.get(p)
@@ -232,12 +253,14 @@ class Adam(_MultiTensorOptimizer):
             if not ps:
                 continue
             rows, sizes = [], []
-            for p in ps:
+            for p in ps:                                  # states first: a new counter may move the whole pool
                 st = self.state[p]
                 if not st:
                     st['step'] = self._step_slot(gi, p)
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
+            for p in ps:
+                st = self.state[p]
                 rows.append((p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
                              st['step'].data_ptr()))
                 sizes.append(p.numel())
