@@ -45,7 +45,7 @@ def main():
         n = max(nf, nw)
         out[k] = {"launches": n, "read_bytes_per_launch": 2 * f * 1024 / max(nf, 1), "write_bytes_per_launch": w * 1024 / max(nw, 1)}
         out[k]["hbm_bytes_per_launch"] = out[k]["read_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
-    json.dump({"command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing",
+    json.dump({"command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing [--launch eager]: per-launch averages over every launch of the run",
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes", "kernels": out},
               open(sys.argv[3], "w"), indent=1)
     tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
