@@ -103,6 +103,20 @@ int ur_conv1x1_pw_fwd_affine(const void* x, const float* in_aff, int in_relu, co
                              const float* bias, void* y, const ur_conv_desc* d, ur_stream_t s);
 int ur_conv1x1_pw_wgrad_affine(const void* x, const float* x_aff, int x_relu, const void* dy, float* dw, void* workspace,
                                size_t ws_bytes, const ur_conv_desc* d, ur_stream_t s);
+/* The same three kernels for a 1x1 convolution over a channel concatenation that is never materialised (the Feature
+ * Merge S/C:280 torch.cat([U_out, Res_out], 1) followed by the head S/C:127-133): logical input channels [0, ca) live in the
+ * dense tensor xa (pitch ld_a, 0 = ca), channels [ca, ca + cb) in xb (pitch ld_b); ca + cb = d->cin, 8 | ca, cb and pitches;
+ * aff_a = [2][ca], aff_b = [2][cb] as in_aff above.  Backward-data writes the two gradients into two dense tensors.  A
+ * 64-channel tensor written as a window of an 80-channel one is 128-byte runs at a 160-byte pitch, i.e. partial lines in
+ * every pass that touches the window; two dense tensors stream at full rate.  d->in_ld is ignored. */
+int ur_conv1x1_pw_fwd_affine_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
+                                  const float* aff_b, int in_relu, const float* w, int w_cout, int w_cin, const float* bias, void* y,
+                                  const ur_conv_desc* d, ur_stream_t s);
+int ur_conv1x1_pw_dgrad_pair(const void* dy, const float* w, int w_cout, int w_cin, void* dxa, int ca, int ld_a, void* dxb, int cb,
+                             int ld_b, const ur_conv_desc* d, ur_stream_t s);
+int ur_conv1x1_pw_wgrad_affine_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
+                                    const float* aff_b, int x_relu, const void* dy, float* dw, void* workspace, size_t ws_bytes,
+                                    const ur_conv_desc* d, ur_stream_t s);
 
 /* ---------------------------------------------------------------- 3x3 / stride 1 / pad 1, bf16: LDS-tiled kernel
  * Same contract as ur_conv2d_fwd / ur_conv2d_dgrad for the layers that carry ~94 % of the FLOPs

@@ -1484,6 +1484,86 @@ def test_batchnorm_folded_into_the_1x1_convolution_matches_the_separate_passes(p
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,ca,cb,h,w,classes", [(2, 64, 16, 256, 160, 19), (1, 64, 16, 301, 219, 19), (2, 8, 16, 200, 170, 5),
+                                                 (1, 32, 24, 263, 251, 8)])
+def test_head_over_the_two_branch_outputs_matches_the_head_over_their_concatenation(pkg, n, ca, cb, h, w, classes):
+    """Feature Merge + segmentation head (S/C:280 torch.cat([u_out, res_out], 1) -> S/C:127-133 BN -> ReLU -> 1x1 conv) with
+    the head's kernels reading the two dense branch outputs (ops.bn_relu_conv1x1_pair) against the same head over the
+    concatenated tensor: output, both input gradients, every parameter gradient and the running statistics.  The BatchNorm
+    statistics are folded from per-workgroup partial sums whose row split depends on the channel count, so the two agree to
+    fp32 rounding of the statistics (not bit for bit); training and eval mode; ragged pixel counts; class counts that are
+    not multiples of 8."""
+    ops, B = pkg.ops, pkg.modules._blocks
+    torch.manual_seed(7)
+    head = B.OutConv(ca + cb, classes).to(DEV)
+    with torch.no_grad():
+        head[0].weight.uniform_(0.5, 1.5); head[0].bias.uniform_(-0.3, 0.3)
+    a0 = torch.randn(n, ca, h, w, device=DEV) * 2 + 0.3
+    b0 = torch.randn(n, cb, h, w, device=DEV) * 0.7 - 0.2
+    g0 = torch.randn(n, classes, h, w, device=DEV)
+    state = {k: v.clone() for k, v in head.state_dict().items()}
+
+    def run(pair, train_mode):
+        head.load_state_dict(state)
+        head.train(train_mode)
+        head.zero_grad(set_to_none=True)
+        xa = ops.as_activation(a0, torch.bfloat16).detach().requires_grad_(True)
+        xb = ops.as_activation(b0, torch.bfloat16).detach().requires_grad_(True)
+        if pair:
+            assert ops.bn_relu_conv1x1_pair_supported(n, ca, cb, h, w, torch.bfloat16, head[0], head[2])
+            out = ops.bn_relu_conv1x1_pair(xa, xb, head[0], head[2])
+            assert out is not None
+        else:
+            out = head(ops.cat_pad(xa, xb))
+        out.backward(ops.as_activation(g0, torch.bfloat16))
+        return (host(pkg, out), host(pkg, xa.grad), host(pkg, xb.grad), {k: p.grad.clone() for k, p in head.named_parameters()},
+                {k: v.clone() for k, v in head.state_dict().items() if "running" in k or "num_batches" in k})
+
+    for train_mode in (True, False):
+        r, p = run(False, train_mode), run(True, train_mode)
+        assert rel_l2(p[0], r[0]) < 1e-3
+        assert rel_l2(p[1], r[1]) < 2e-3 and rel_l2(p[2], r[2]) < 2e-3
+        for k in r[3]:
+            assert rel_l2(p[3][k].cpu(), r[3][k].cpu()) < 2e-3, k
+        for k in r[4]:
+            assert torch.allclose(r[4][k].float(), p[4][k].float(), rtol=1e-5, atol=1e-6), k
+        if not train_mode:                  # no statistics pass: the same constants, the same products in the same order
+            assert torch.equal(p[0], r[0])
+
+
+@pytest.mark.gpu
+def test_two_branch_model_without_the_merged_tensor_matches_the_model_with_it(pkg):
+    """UResNetNewEUCB (S/C:214-345) with the Feature Merge read as two tensors by the head against the same model writing
+    both branches into one 80-channel tensor: loss and every gradient after one backward pass agree to bf16 rounding."""
+    M, train, ops = pkg.modules.U_ResNet, pkg.train, pkg.ops
+
+    def run(pair):
+        old, ops.fuse_merge_into_head = ops.fuse_merge_into_head, pair
+        try:
+            torch.manual_seed(0)
+            m = M.UResNetNewEUCB(19, 3, 64).set_compute_dtype(torch.bfloat16).to(DEV).train()
+            g = torch.Generator().manual_seed(5)
+            x = torch.randn(2, 3, 128, 256, generator=g).to(DEV)
+            y = torch.randint(0, 19, (2, 128, 256), generator=g).to(DEV)
+            ops.kernel_timings, ops.kernel_timing_tags = [], {"pw_fwd"}
+            logits = m(x)
+            calls = len(ops.kernel_timings)
+            ops.kernel_timings, ops.kernel_timing_tags = None, None
+            loss = train.compute_loss(logits, y)
+            loss.backward()
+            torch.cuda.synchronize()
+            return loss.item(), host(pkg, logits), {k: p.grad.clone().cpu() for k, p in m.named_parameters()}, calls
+        finally:
+            ops.fuse_merge_into_head, ops.kernel_timings, ops.kernel_timing_tags = old, None, None
+
+    a, b = run(False), run(True)
+    assert abs(a[0] - b[0]) < 2e-3 * abs(a[0])
+    assert rel_l2(b[1], a[1]) < 5e-3
+    for k in a[2]:
+        assert rel_l2(b[2][k], a[2][k]) < 5e-2, k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("into_window", [False, True])
 def test_eucb2_with_the_last_batchnorm_folded_into_the_projection(pkg, into_window):
     """EUCB* (S/C:59-87) at a size where the streaming 1x1 kernels serve all three directions: the last stage's BatchNorm+ReLU

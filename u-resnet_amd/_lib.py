@@ -44,6 +44,9 @@ SIGNATURES = {
     "ur_conv1x1_pw_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
     "ur_conv1x1_pw_fwd_affine": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _dp, _vp]),
     "ur_conv1x1_pw_wgrad_affine": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _dp, _vp]),
+    "ur_conv1x1_pw_fwd_affine_pair": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _dp, _vp]),
+    "ur_conv1x1_pw_dgrad_pair": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _dp, _vp]),
+    "ur_conv1x1_pw_wgrad_affine_pair": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _dp, _vp]),
     "ur_conv2d_wgrad_workspace": (_sz, [_dp]),
     "ur_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _dp, _vp]),
     "ur_conv3x3_tile_supported": (_i, [_dp, _i]),

@@ -35,6 +35,11 @@ struct PwParams {
     int flat;                  // output rows are contiguous in memory and in LDS (out_ld == M): copy the chunk as bytes
     const float* in_aff;       // AFF: [2][K] per-channel scale then shift applied to x on its way into LDS (a folded BatchNorm)
     int in_relu;               // AFF: ReLU after the multiply-add
+    // A logical tensor that lives in two dense ones (a channel concatenation that was never materialised): input channels
+    // [K1, K) come from x2 (pitch in_ld2, constants in_aff2 = [2][K - K1]) when x2 is set; output channels [M1, M) go to
+    // y2 (pitch out_ld2) when y2 is set.  All boundaries are multiples of 8 channels (whole 16-byte pieces).
+    const bf16_t* x2; int K1, in_ld2; const float* in_aff2;
+    bf16_t* y2; int M1, out_ld2;
 };
 
 // x -> bf16(max(x * scale + shift, 0)) on 8 consecutive channels; cs = the channels' scales in LDS, their shifts K floats on
@@ -70,7 +75,11 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     const float* aff = reinterpret_cast<const float*>(lds + (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out));
     if constexpr (AFF) {
         float* a = const_cast<float*>(aff);
-        for (int i = threadIdx.x; i < 2 * p.K; i += NT) a[i] = p.in_aff[i];
+        const int ka = p.in_aff2 ? p.K1 : p.K;                 // channels whose constants are in in_aff
+        for (int i = threadIdx.x; i < 2 * p.K; i += NT) {
+            const int which = i >= p.K ? 1 : 0, c = i - which * p.K;
+            a[i] = c < ka ? p.in_aff[which * ka + c] : p.in_aff2[which * (p.K - ka) + c - ka];
+        }
         __syncthreads();
     }
 
@@ -103,12 +112,14 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     // input pieces of a chunk: piece = i*64 + lane -> (pixel, 8-channel group); the same for every chunk
     const int gi = p.K >> 3, pieces_in = 32 * gi;
     int ipix[KS], isrc[KS], ilds[KS], ich[AFF ? KS : 1];
+    bool isecond[KS];                                          // the piece comes from the second tensor
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
         const int id = i * 64 + lane;
         const int pix = id / gi, grp = id - pix * gi;
         ipix[i] = id < pieces_in ? pix : 32;                   // 32: no such piece
-        isrc[i] = pix * p.in_ld + grp * 8;
+        isecond[i] = p.x2 != nullptr && grp * 8 >= p.K1;
+        isrc[i] = isecond[i] ? pix * p.in_ld2 + grp * 8 - p.K1 : pix * p.in_ld + grp * 8;
         ilds[i] = pix * p.pitch_in + grp * 16;
         if constexpr (AFF) ich[i] = grp * 8;
     }
@@ -116,14 +127,18 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     constexpr int NO = 2 * MT;
     const int go = p.M >> 3, pieces_out = p.flat ? (32 * p.M * 2) / 16 : 32 * go;
     int opix[NO], odst[NO], olds[NO];
+    bool osecond[NO];                                          // the piece goes to the second tensor
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
         const int id = i * 64 + lane;
+        osecond[i] = false;
         if (p.flat) {
             opix[i] = id < pieces_out ? 0 : 32; odst[i] = id * 8; olds[i] = id * 16;
         } else {
             const int pix = id / (go > 0 ? go : 1), grp = id - pix * go;
-            opix[i] = id < pieces_out ? pix : 32; odst[i] = pix * p.out_ld + grp * 8; olds[i] = pix * p.pitch_out + grp * 16;
+            osecond[i] = p.y2 != nullptr && grp * 8 >= p.M1;
+            opix[i] = id < pieces_out ? pix : 32; olds[i] = pix * p.pitch_out + grp * 16;
+            odst[i] = osecond[i] ? pix * p.out_ld2 + grp * 8 - p.M1 : pix * p.out_ld + grp * 8;
         }
     }
 
@@ -135,10 +150,13 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     auto fetch = [&](long long chunk, bf16x8_t* dst) {
         const long long first = chunk * 32;
         const bf16_t* src = p.x + first * p.in_ld;
+        const bf16_t* src2 = p.x2 ? p.x2 + first * p.in_ld2 : src;
         const int live = (int)(p.P - first < 32 ? p.P - first : 32);
 #pragma unroll
-        for (int i = 0; i < KS; ++i)
-            dst[i] = ipix[i] < live ? (UR_PW_NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(src + isrc[i])) : *reinterpret_cast<const bf16x8_t*>(src + isrc[i])) : zero;
+        for (int i = 0; i < KS; ++i) {
+            const bf16x8_t* q = reinterpret_cast<const bf16x8_t*>((isecond[i] ? src2 : src) + isrc[i]);
+            dst[i] = ipix[i] < live ? (UR_PW_NT ? __builtin_nontemporal_load(q) : *q) : zero;
+        }
     };
 
     bf16x8_t nxt[KS];
@@ -204,12 +222,14 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             bf16_t* out = p.y + first * p.out_ld;
+            bf16_t* out2 = p.y2 ? p.y2 + first * p.out_ld2 : out;
 #pragma unroll
             for (int i = 0; i < NO; ++i)
                 if (opix[i] < live) {
                     const bf16x8_t o8 = *reinterpret_cast<const bf16x8_t*>(lout + olds[i]);
-                    if (UR_PW_NT) __builtin_nontemporal_store(o8, reinterpret_cast<bf16x8_t*>(out + odst[i]));
-                    else *reinterpret_cast<bf16x8_t*>(out + odst[i]) = o8;
+                    bf16x8_t* q = reinterpret_cast<bf16x8_t*>((osecond[i] ? out2 : out) + odst[i]);
+                    if (UR_PW_NT) __builtin_nontemporal_store(o8, q);
+                    else *q = o8;
                 }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -279,6 +299,14 @@ int launch(PwParams p, hipStream_t st) {
     p.pitch_out = p.flat ? p.M * 2 : odd_pitch(p.M * 2);
     UR_REQUIRE(lds_bytes(p.K, p.M, p.out_ld) + 2 * p.K * sizeof(float) <= 64 * 1024, "conv1x1_pw: %d -> %d channels exceeds the LDS budget", p.K, p.M);
     UR_REQUIRE(!p.in_aff || ((uintptr_t)p.in_aff & 3) == 0, "conv1x1_pw: misaligned input constants");
+    if (p.x2)
+        UR_REQUIRE(p.K1 > 0 && p.K1 < p.K && p.K1 % 8 == 0 && p.in_ld2 % 8 == 0 && p.in_ld2 >= p.K - p.K1 && p.in_ld >= p.K1 &&
+                       ((uintptr_t)p.x2 & 15) == 0 && (!p.in_aff || p.in_aff2),
+                   "conv1x1_pw: the two-tensor input needs 8 | channel split and pitches, 16-byte alignment and constants for both");
+    if (p.y2)
+        UR_REQUIRE(!p.flat && p.M1 > 0 && p.M1 < p.M && p.M1 % 8 == 0 && p.out_ld2 % 8 == 0 && p.out_ld2 >= p.M - p.M1 &&
+                       p.out_ld >= p.M1 && ((uintptr_t)p.y2 & 15) == 0,
+                   "conv1x1_pw: the two-tensor output needs 8 | channel split and pitches and 16-byte alignment");
     if (p.P <= 0) return UR_OK;
     const long long chunks = (p.P + 31) / 32;
     switch (mt) {
@@ -327,6 +355,38 @@ int ur_conv1x1_pw_fwd_affine(const void* x, const float* in_aff, int in_relu, co
     p.K = d->cin; p.M = d->cout; p.in_ld = d->in_ld ? d->in_ld : d->cin; p.out_ld = d->out_ld ? d->out_ld : d->cout;
     p.wM = w_cout; p.wK = w_cin; p.sm = w_cin; p.sk = 1;
     p.in_aff = in_aff; p.in_relu = in_relu;
+    return launch(p, (hipStream_t)s);
+}
+
+int ur_conv1x1_pw_fwd_affine_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
+                                  const float* aff_b, int in_relu, const float* w, int w_cout, int w_cin, const float* bias, void* y,
+                                  const ur_conv_desc* d, ur_stream_t s) {
+    UR_REQUIRE(xa && xb && aff_a && aff_b && w && y && d, "conv1x1_pw_fwd_affine_pair: null argument");
+    UR_REQUIRE(shape_ok(d), "conv1x1_pw_fwd_affine_pair: not a bf16 1x1 stride-1 convolution");
+    UR_REQUIRE(ca + cb == d->cin && w_cout <= d->cout && w_cin <= d->cin,
+               "conv1x1_pw_fwd_affine_pair: %d + %d channels against a descriptor of %d, weight %dx%d", ca, cb, d->cin, w_cout, w_cin);
+    PwParams p{};
+    p.x = (const bf16_t*)xa; p.w = w; p.bias = bias; p.y = (bf16_t*)y;
+    p.P = (long long)d->n * d->h * d->w;
+    p.K = d->cin; p.M = d->cout; p.in_ld = ld_a ? ld_a : ca; p.out_ld = d->out_ld ? d->out_ld : d->cout;
+    p.wM = w_cout; p.wK = w_cin; p.sm = w_cin; p.sk = 1;
+    p.in_aff = aff_a; p.in_relu = in_relu;
+    p.x2 = (const bf16_t*)xb; p.K1 = ca; p.in_ld2 = ld_b ? ld_b : cb; p.in_aff2 = aff_b;
+    return launch(p, (hipStream_t)s);
+}
+
+int ur_conv1x1_pw_dgrad_pair(const void* dy, const float* w, int w_cout, int w_cin, void* dxa, int ca, int ld_a, void* dxb, int cb,
+                             int ld_b, const ur_conv_desc* d, ur_stream_t s) {
+    UR_REQUIRE(dy && w && dxa && dxb && d, "conv1x1_pw_dgrad_pair: null argument");
+    UR_REQUIRE(shape_ok(d), "conv1x1_pw_dgrad_pair: not a bf16 1x1 stride-1 convolution");
+    UR_REQUIRE(ca + cb == d->cin && w_cout <= d->cout && w_cin <= d->cin,
+               "conv1x1_pw_dgrad_pair: %d + %d channels against a descriptor of %d, weight %dx%d", ca, cb, d->cin, w_cout, w_cin);
+    PwParams p{};
+    p.x = (const bf16_t*)dy; p.w = w; p.bias = nullptr; p.y = (bf16_t*)dxa;
+    p.P = (long long)d->n * d->h * d->w;
+    p.K = d->cout; p.M = d->cin; p.in_ld = d->out_ld ? d->out_ld : d->cout; p.out_ld = ld_a ? ld_a : ca;
+    p.wM = w_cin; p.wK = w_cout; p.sm = 1; p.sk = w_cin;
+    p.y2 = (bf16_t*)dxb; p.M1 = ca; p.out_ld2 = ld_b ? ld_b : cb;
     return launch(p, (hipStream_t)s);
 }
 

@@ -29,6 +29,9 @@ struct PwWgParams {
     const float* x_aff;  // AFF: [2][K] per-channel scale then shift applied to x on its way into LDS (a folded BatchNorm)
     int x_relu;          // AFF: ReLU after the multiply-add
     int aff_off;         // AFF: byte offset of the constants inside the dynamic LDS (behind the staging rows and the sum buffer)
+    // x as two dense tensors (a channel concatenation that was never materialised): channels [K1, K) come from x2 (pitch
+    // ld_x2, constants x_aff2 = [2][K - K1]) when x2 is set; K1 is a multiple of 8
+    const bf16_t* x2; int K1, ld_x2; const float* x_aff2;
 };
 
 // x -> bf16(max(x * scale + shift, 0)) on 8 consecutive channels; cs = the channels' scales in LDS, their shifts K floats on
@@ -62,7 +65,11 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
     const float* aff = reinterpret_cast<const float*>(lds + p.aff_off);
     if constexpr (AFF) {
         float* a = const_cast<float*>(aff);
-        for (int i = threadIdx.x; i < 2 * p.K; i += NT) a[i] = p.x_aff[i];
+        const int ka = p.x_aff2 ? p.K1 : p.K;
+        for (int i = threadIdx.x; i < 2 * p.K; i += NT) {
+            const int which = i >= p.K ? 1 : 0, c = i - which * p.K;
+            a[i] = c < ka ? p.x_aff[which * ka + c] : p.x_aff2[which * (p.K - ka) + c - ka];
+        }
         __syncthreads();
     }
 
@@ -70,11 +77,13 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
     const int gx = p.K >> 3, gy = p.M >> 3;
     constexpr int XL = KB, YL = MB;                       // loads per lane: 32 * gx <= 64 KB pieces, 32 * gy <= 64 MB
     int xpix[XL], xsrc[XL], xlds[XL], ypix[YL], ysrc[YL], ylds[YL], xch[AFF ? XL : 1];
+    bool xsecond[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
         const int id = i * 64 + lane, pix = id / gx, grp = id - pix * gx;
         xpix[i] = id < 32 * gx ? pix : 1 << 20;
-        xsrc[i] = pix * p.ld_x + grp * 8;
+        xsecond[i] = p.x2 != nullptr && grp * 8 >= p.K1;
+        xsrc[i] = xsecond[i] ? pix * p.ld_x2 + grp * 8 - p.K1 : pix * p.ld_x + grp * 8;
         xlds[i] = pix * p.pitch_x + grp * 16;
         if constexpr (AFF) xch[i] = grp * 8;
     }
@@ -111,10 +120,11 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
         const long long first = chunk * 32;
         const int live = (int)(p.P - first < 32 ? p.P - first : 32);
         const bf16_t* xb = p.x + first * p.ld_x;
+        const bf16_t* xb2 = p.x2 ? p.x2 + first * p.ld_x2 : xb;
         const bf16_t* yb = p.dy + first * p.ld_dy;
 #pragma unroll
         for (int i = 0; i < XL; ++i)
-            xv[i] = xpix[i] < live ? *reinterpret_cast<const bf16x8_t*>(xb + xsrc[i]) : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            xv[i] = xpix[i] < live ? *reinterpret_cast<const bf16x8_t*>((xsecond[i] ? xb2 : xb) + xsrc[i]) : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < YL; ++i)
             yv[i] = ypix[i] < live ? *reinterpret_cast<const bf16x8_t*>(yb + ysrc[i]) : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
@@ -230,8 +240,9 @@ size_t ur_conv1x1_pw_wgrad_workspace(const ur_conv_desc* d) {
 }  // extern "C"
 
 namespace {
+struct PwWgSecond { const void* x2; int k1, ld_x2; const float* aff2; };
 int pw_wgrad_launch(const void* x, const float* x_aff, int x_relu, const void* dy, float* dw, void* workspace, size_t ws_bytes,
-                    const ur_conv_desc* d, ur_stream_t s) {
+                    const ur_conv_desc* d, ur_stream_t s, const PwWgSecond* second = nullptr) {
     Cfg c;
     UR_REQUIRE(shape_ok(d) && pick(d, c), "conv1x1_pw_wgrad: needs bf16, 1x1 stride 1, 8 | channels and pitches, cout <= 32, cin <= 96");
     UR_REQUIRE(x && dy && dw && workspace, "conv1x1_pw_wgrad: null pointer");
@@ -243,6 +254,13 @@ int pw_wgrad_launch(const void* x, const float* x_aff, int x_relu, const void* d
     p.K = d->cin; p.M = d->cout; p.ld_x = d->in_ld; p.ld_dy = d->out_ld;
     p.pitch_x = odd_pitch(c.kb * 32); p.pitch_y = odd_pitch(c.mb * 32);
     UR_REQUIRE(p.P * (p.ld_x > p.ld_dy ? p.ld_x : p.ld_dy) < (1LL << 31), "conv1x1_pw_wgrad: tensor exceeds 2^31 elements");
+    if (second) {
+        UR_REQUIRE(second->x2 && second->k1 > 0 && second->k1 < p.K && second->k1 % 8 == 0 && second->ld_x2 % 8 == 0 &&
+                       second->ld_x2 >= p.K - second->k1 && ((uintptr_t)second->x2 % 16) == 0 && (!x_aff || second->aff2) &&
+                       p.P * second->ld_x2 < (1LL << 31),
+                   "conv1x1_pw_wgrad: the two-tensor input needs 8 | channel split and pitch, 16-byte alignment and constants for both");
+        p.x2 = (const bf16_t*)second->x2; p.K1 = second->k1; p.ld_x2 = second->ld_x2; p.x_aff2 = second->aff2;
+    }
     size_t lds = lds_bytes(c);
     if (x_aff) {                                   // the input's constants sit behind the staging rows / sum buffer
         lds = (lds + 15) / 16 * 16;
@@ -287,6 +305,18 @@ int ur_conv1x1_pw_wgrad_affine(const void* x, const float* x_aff, int x_relu, co
                                size_t ws_bytes, const ur_conv_desc* d, ur_stream_t s) {
     UR_REQUIRE(x_aff, "conv1x1_pw_wgrad_affine: null constants");
     return pw_wgrad_launch(x, x_aff, x_relu, dy, dw, workspace, ws_bytes, d, s);
+}
+
+int ur_conv1x1_pw_wgrad_affine_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
+                                    const float* aff_b, int x_relu, const void* dy, float* dw, void* workspace, size_t ws_bytes,
+                                    const ur_conv_desc* d, ur_stream_t s) {
+    UR_REQUIRE(xa && xb && aff_a && aff_b && d, "conv1x1_pw_wgrad_affine_pair: null argument");
+    UR_REQUIRE(ca + cb == d->cin, "conv1x1_pw_wgrad_affine_pair: %d + %d channels against a descriptor of %d", ca, cb, d->cin);
+    ur_conv_desc da = *d;
+    da.in_ld = ld_a ? ld_a : ca;
+    UR_REQUIRE(da.in_ld % 8 == 0 && da.in_ld >= ca, "conv1x1_pw_wgrad_affine_pair: bad pitch of the first tensor");
+    const PwWgSecond second{xb, ca, ld_b ? ld_b : cb, aff_b};
+    return pw_wgrad_launch(xa, aff_a, x_relu, dy, dw, workspace, ws_bytes, &da, s, &second);
 }
 
 }  // extern "C"

@@ -49,6 +49,23 @@ class _TwoBranch(ResTrunk):
             res = self._res_forward(x)
         n, _, h, w = x.shape
         c_u, c_res = self.up4.conv[3].out_channels, self.out_conv[0].num_features - self.up4.conv[3].out_channels
+        head_conv = self.out_conv[2]
+        if (res.shape[2] * 2 == h and res.shape[3] * 2 == w and not has_hooks(self.out_conv, *self.out_conv)
+                and head_conv.stride == (1, 1) and head_conv.padding == (0, 0) and head_conv.groups == 1
+                and head_conv.dilation == (1, 1)
+                and ops.bn_relu_conv1x1_pair_supported(n, c_u, c_res, h, w, x.dtype, self.out_conv[0], head_conv)):
+            # Feature Merge without a merged tensor (S/C:280 torch.cat([u_out, res_out], dim=1) -> S/C:344 out_conv): both
+            # branches keep their dense results and the head's kernels read the pair.  (Channel windows of one 80-channel
+            # tensor are 128- and 32-byte runs at a 160-byte pitch: partial memory lines in every pass that touches them.)
+            with on_side():
+                res_out = self.Upsample(res)
+            u_out = unet_branch_forward(self, x)
+            if fork is not None:
+                fork.join(res_out)
+            z = ops.bn_relu_conv1x1_pair(ops.dense(u_out), ops.dense(res_out), self.out_conv[0], head_conv)
+            if z is not None:
+                return z
+            return self.out_conv(ops.cat_pad(u_out, res_out))
         if (isinstance(self.Upsample, (EUCB, EUCB2)) and not has_hooks(self.Upsample, self.up4, self.up4.conv)
                 and res.shape[2] * 2 == h and res.shape[3] * 2 == w and self.Upsample.out_channels == c_res):
             # Feature Merge without copies: both branches write their result into its channel window of the merged

@@ -1113,6 +1113,138 @@ def bn_relu_conv1x1(y, bn, conv, stats=None, out=None):
                                 None if out is None else (out,))
 
 
+class _BNReluConv1x1Pair(Function):
+    """_BNReluConv1x1 over a channel concatenation that is never materialised: conv1x1(relu(BatchNorm(cat([ya, yb], 1)))).
+    The BatchNorm is per channel, so its statistics, constants and backward passes run on the two dense tensors separately
+    (slices of the parameter vectors); the streaming 1x1 kernels read both tensors (ur_conv1x1_pw_*_pair).  A 64-channel
+    window of an 80-channel tensor is 128-byte runs at a 160-byte pitch -- partial memory lines in every pass that touches it;
+    two dense tensors stream at full rate."""
+
+    @staticmethod
+    def forward(ctx, ya, yb, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, weight, bias):
+        _require_gpu(ya)
+        n, ca, h, w = ya.shape
+        cb = yb.shape[1]
+        c = ca + cb
+        rows, dev = n * h * w, ya.device
+        cout = weight.shape[0]
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        affs = (torch.empty(2 * ca, dtype=torch.float32, device=dev), torch.empty(2 * cb, dtype=torch.float32, device=dev))
+        parts = ((ya, 0, ca, affs[0]), (yb, ca, cb, affs[1]))
+        off = lambda t, o: None if t is None else t.data_ptr() + 4 * o      # noqa: E731  (fp32 vectors: element o)
+        if training:
+            for y, o, ci, aff in parts:
+                stats = torch.empty((query("ur_bn_stats_rows", rows, ci), ci, 2), dtype=torch.float32, device=dev)
+                call("ur_bn_stats", y.data_ptr(), _dt(y), rows, ci, stats.data_ptr(), _stream())
+                call("ur_bn_finalize_affine", stats.data_ptr(), stats.shape[0], rows, ci, eps, momentum, off(mean, o), off(invstd, o),
+                     off(running_mean, o), off(running_var, o), _p(nbt) if o == 0 else None, off(gamma, o), off(beta, o),
+                     aff.data_ptr(), _stream())
+        else:
+            call("ur_bn_eval_prepare", running_mean.data_ptr(), running_var.data_ptr(), c, eps, mean.data_ptr(),
+                 invstd.data_ptr(), _stream())
+            for y, o, ci, aff in parts:
+                call("ur_bn_eval_affine", off(running_mean, o), off(running_var, o), off(gamma, o), off(beta, o), ci, eps,
+                     aff.data_ptr(), aff.data_ptr() + 4 * ci, _stream())
+        z = empty_nhwc(n, cout, h, w, ya.dtype, dev)
+        d, dbk = _pw_descs((n, c, h, w), cout, ya.dtype, c, cout)
+        with _Timed("pw_fwd", _conv_flops(d), d):
+            call("ur_conv1x1_pw_fwd_affine_pair", ya.data_ptr(), ca, ca, yb.data_ptr(), cb, cb, affs[0].data_ptr(),
+                 affs[1].data_ptr(), 1, weight.data_ptr(), cout, c, _p(bias), z.data_ptr(), C.byref(d), _stream())
+        ctx.save_for_backward(ya, yb, weight, gamma, beta, mean, invstd, affs[0], affs[1])
+        ctx.dbk, ctx.bias, ctx.eval = dbk, bias, not training
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        ya, yb, weight, gamma, beta, mean, invstd, aff_a, aff_b = ctx.saved_tensors
+        d = ctx.dbk
+        n, ca, h, w = ya.shape
+        cb = yb.shape[1]
+        c = ca + cb
+        rows, dev = n * h * w, ya.device
+        cout = weight.shape[0]
+        dz, dz_ld = _g(dz), cout
+        db = dw = None
+        if ctx.bias is not None and ctx.needs_input_grad[11]:
+            db = _colsum(dz.data_ptr(), d.dtype, rows, cout, dz_ld, dev, ctx.bias)
+        if d.cout != cout:
+            dz, dz_ld = _pad_channels(dz, d.cout), d.cout
+        d.out_ld = dz_ld
+        # gradients of the two halves of the activated tensor a = relu(BatchNorm(cat)), which exists in no buffer
+        da = (empty_nhwc(n, ca, h, w, ya.dtype, dev), empty_nhwc(n, cb, h, w, ya.dtype, dev))
+        with _Timed("pw_dgrad", _conv_flops(d), d):
+            call("ur_conv1x1_pw_dgrad_pair", dz.data_ptr(), weight.data_ptr(), cout, c, da[0].data_ptr(), ca, ca, da[1].data_ptr(),
+                 cb, cb, C.byref(d), _stream())
+        if ctx.needs_input_grad[10]:
+            dw = grad_buffer(weight, (d.cout, c, 1, 1))
+            ws = _workspace(query("ur_conv1x1_pw_wgrad_workspace", C.byref(d)), dev)
+            with _Timed("pw_wgrad", _conv_flops(d), d):
+                call("ur_conv1x1_pw_wgrad_affine_pair", ya.data_ptr(), ca, ca, yb.data_ptr(), cb, cb, aff_a.data_ptr(),
+                     aff_b.data_ptr(), 1, dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(d), _stream())
+            if d.cout != cout:
+                dw = dw[:cout].contiguous()
+        dgamma, dbeta = grad_buffer(gamma), grad_buffer(beta)
+        off = lambda t, o: t.data_ptr() + 4 * o      # noqa: E731
+        dys = []
+        for y, g, o, ci in ((ya, da[0], 0, ca), (yb, da[1], ca, cb)):
+            tb = y.numel() * y.element_size()
+            partial = torch.empty((query("ur_bn_stats_rows", rows, ci), ci, 2), dtype=torch.float32, device=dev)
+            with _Timed("hbm:bn_bwd_reduce", tb * 2):
+                call("ur_bn_act_bwd_reduce", g.data_ptr(), y.data_ptr(), None, off(mean, o), off(invstd, o), off(gamma, o),
+                     off(beta, o), _lib.ACT_RELU, _dt(y), rows, ci, ci, partial.data_ptr(), _stream())
+            sums = torch.empty((ci, 2), dtype=torch.float32, device=dev)
+            call("ur_bn_bwd_finalize", partial.data_ptr(), partial.shape[0], ci, sums.data_ptr(), off(dgamma, o), off(dbeta, o),
+                 _stream())
+            dy = torch.empty_like(y, memory_format=CL)
+            with _Timed("hbm:bn_bwd_apply", tb * 3):
+                call("ur_bn_act_bwd_apply", g.data_ptr(), y.data_ptr(), None, off(mean, o), off(invstd, o), off(gamma, o),
+                     off(beta, o), sums.data_ptr(), _lib.ACT_RELU, int(ctx.eval), dy.data_ptr(), None, _dt(y), rows, ci, ci,
+                     _stream())
+            dys.append(dy)
+        return dys[0], dys[1], dgamma, dbeta, None, None, None, None, None, None, dw, db
+
+
+fuse_merge_into_head = os.environ.get("URESNET_MERGE_PAIR", "1") != "0"    # False: the Feature Merge builds the merged tensor
+
+
+def bn_relu_conv1x1_pair_supported(n, ca, cb, h, w, dtype, bn, conv):
+    """Whether bn_relu_conv1x1_pair covers conv(relu(bn(cat))) for two dense bf16 tensors of ca and cb channels."""
+    weight = conv.weight
+    c = ca + cb
+    if not (fuse_merge_into_head and fuse_bn_into_conv1x1 and use_pw_kernel) or dtype != torch.bfloat16 or ca % 8 or cb % 8:
+        return False
+    if (tuple(weight.shape[2:]) != (1, 1) or weight.dtype != torch.float32 or not weight.is_contiguous() or weight.shape[1] != c
+            or bn.num_features != c or not weight.is_cuda):
+        return False
+    if (bn.training or bn.running_mean is None) and bn.momentum is None:
+        return False
+    cout = weight.shape[0]
+    d, dbk = _pw_descs((n, c, h, w), cout, dtype, c, cout)
+    dbk.out_ld = dbk.cout
+    return bool(query("ur_conv1x1_pw_supported", C.byref(d), 0) and query("ur_conv1x1_pw_supported", C.byref(dbk), 1)
+                and query("ur_conv1x1_pw_wgrad_supported", C.byref(dbk)))
+
+
+def bn_relu_conv1x1_pair(ya, yb, bn, conv):
+    """conv(relu(bn(cat([ya, yb], 1)))) for a BatchNorm2d `bn` over both tensors' channels and a 1x1 stride-1 Conv2d `conv`,
+    without the concatenated tensor (_BNReluConv1x1Pair); None where the streaming kernels do not cover the shape (the caller
+    then concatenates)."""
+    for y in (ya, yb):
+        if not y.is_cuda or y.dim() != 4 or not _is_nhwc_dense(y) or y.data_ptr() % 16:
+            return None
+    if (tuple(ya.shape[2:]) != tuple(yb.shape[2:]) or ya.shape[0] != yb.shape[0] or ya.dtype != yb.dtype
+            or not bn_relu_conv1x1_pair_supported(ya.shape[0], ya.shape[1], yb.shape[1], ya.shape[2], ya.shape[3], ya.dtype, bn, conv)):
+        return None
+    training = bn.training or bn.running_mean is None
+    track = training and bn.track_running_stats and bn.running_mean is not None
+    return _BNReluConv1x1Pair.apply(ya, yb, bn.weight, bn.bias,
+                                    bn.running_mean if (track or not training) else None,
+                                    bn.running_var if (track or not training) else None,
+                                    bn.num_batches_tracked if track else None,
+                                    training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, conv.weight, conv.bias)
+
+
 # ------------------------------------------------------------------------------ spatial ops
 class _MaxPool2x2(Function):
     @staticmethod
