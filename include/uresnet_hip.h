@@ -256,6 +256,13 @@ int ur_bn_eval_affine(const float* running_mean, const float* running_var, const
 int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const void* residual, int act, void* z, int dtype, long long rows, int c, int z_ld,
                   ur_stream_t s);
+/* ur_bn_act_fwd (no residual) and ur_maxpool2x2_fwd of its result in one pass, for an encoder stage whose output feeds both
+ * the skip connection and the next stage's MaxPool2d(2, 2) (S/C:105, S/C:268-276): z (pitch z_ld, 0 = dense), pooled
+ * [n][h/2][w/2][c] and idx (one position byte per pooled element) are bit for bit what the two calls produce; the pooling
+ * pass no longer reads z back.  bf16, even h and w, c a power of two in [8, 2048]. */
+int ur_bn_act_fwd_pool_supported(int dtype, int n, int h, int w, int c);
+int ur_bn_act_fwd_pool(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                       void* z, int z_ld, void* pooled, uint8_t* idx, int dtype, int n, int h, int w, int c, ur_stream_t s);
 /* backward pass 1: partial[nparts][c][2] = (sum g, sum g*xhat), g = dz masked by the ReLU (act != 0).
  * The mask comes from the saved output z when z != NULL, else it is recomputed from y (needs gamma, beta;
  * valid only when no residual was added before the activation).  dz_ld = channel pitch of dz in elements

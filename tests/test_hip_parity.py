@@ -1484,6 +1484,71 @@ def test_batchnorm_folded_into_the_1x1_convolution_matches_the_separate_passes(p
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,c,h,w,window", [(2, 64, 64, 96, True), (1, 128, 38, 50, True), (3, 8, 6, 10, False), (1, 512, 16, 32, True)])
+def test_batchnorm_relu_with_the_max_pool_in_the_same_pass_is_bit_identical(pkg, n, c, h, w, window):
+    """DoubleConv's last BatchNorm+ReLU followed by Down's MaxPool2d(2, 2) (S/C:98-99 -> S/C:105) as one pass
+    (ur_bn_act_fwd_pool) against ur_bn_act_fwd + ur_maxpool2x2_fwd: activated tensor (dense and written into the skip half
+    of a concatenated tensor), pooled tensor and position bytes bit-identical, ties and exact zeros after the ReLU included
+    (a quarter of the windows are all zero, where the first position must win)."""
+    ops, L = pkg.ops, pkg._lib
+    import ctypes as C
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(c + h)
+    y = ops.as_activation((torch.randn(n, c, h, w, generator=g) - 0.3).to(DEV), torch.bfloat16)
+    mean, invstd = torch.randn(c, generator=g).to(DEV) * 0.1, torch.rand(c, generator=g).to(DEV) + 0.5
+    gamma, beta = torch.rand(c, generator=g).to(DEV) + 0.5, torch.randn(c, generator=g).to(DEV) * 0.3
+    assert L.query("ur_bn_act_fwd_pool_supported", L.UR_BF16, n, h, w, c)
+    ld = 2 * c if window else c
+
+    def run(fused):
+        z = torch.zeros(n, h, w, ld, dtype=torch.bfloat16, device=DEV)
+        pooled = torch.empty(n, h // 2, w // 2, c, dtype=torch.bfloat16, device=DEV)
+        idx = torch.empty(n, h // 2, w // 2, c, dtype=torch.uint8, device=DEV)
+        if fused:
+            L.call("ur_bn_act_fwd_pool", vp(y), vp(mean), vp(invstd), vp(gamma), vp(beta), 1, vp(z), ld, vp(pooled), vp(idx),
+                   L.UR_BF16, n, h, w, c, st)
+        else:
+            L.call("ur_bn_act_fwd", vp(y), vp(mean), vp(invstd), vp(gamma), vp(beta), None, 1, vp(z), L.UR_BF16, n * h * w, c, ld, st)
+            L.call("ur_maxpool2x2_fwd", vp(z), vp(pooled), vp(idx), L.UR_BF16, n, h, w, c, ld, st)
+        return z, pooled, idx
+
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_pooling_inside_the_batchnorm_pass_leaves_the_training_step_bit_identical(pkg):
+    """UResNetNewEUCB: one optimiser step with the encoder stages' max-pool taken from their BatchNorm pass against the
+    separate pooling pass: loss, logits and every updated parameter bit-identical, and the pooling pass really is gone
+    (four launches per forward without the fusion, none with it)."""
+    M, train, ops = pkg.modules.U_ResNet, pkg.train, pkg.ops
+
+    def run(fused):
+        old, ops.fuse_bn_pool = ops.fuse_bn_pool, fused
+        try:
+            torch.manual_seed(0)
+            m = M.UResNetNewEUCB(19, 3, 16).set_compute_dtype(torch.bfloat16).to(DEV).train()
+            opt = train.Adam(m.parameters(), lr=1e-3)
+            g = torch.Generator().manual_seed(9)
+            x = torch.randn(2, 3, 64, 96, generator=g).to(DEV)
+            y = torch.randint(0, 19, (2, 64, 96), generator=g).to(DEV)
+            ops.kernel_timings, ops.kernel_timing_tags = [], {"hbm:maxpool_fwd", "hbm:bn_fwd_pool"}
+            loss, out = train.seg_train_step(m, opt, x, y)
+            tags = [t[0] for t in ops.kernel_timings]
+            torch.cuda.synchronize()
+            return loss.item(), out.clone(), [p.detach().clone() for p in m.parameters()], tags
+        finally:
+            ops.fuse_bn_pool, ops.kernel_timings, ops.kernel_timing_tags = old, None, None
+
+    a, b = run(False), run(True)
+    assert a[3].count("hbm:maxpool_fwd") == 4 and b[3].count("hbm:maxpool_fwd") == 0 and b[3].count("hbm:bn_fwd_pool") == 4
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
+    for p, q in zip(a[2], b[2]):
+        assert torch.equal(p, q)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,ca,cb,h,w,classes", [(2, 64, 16, 256, 160, 19), (1, 64, 16, 301, 219, 19), (2, 8, 16, 200, 170, 5),
                                                  (1, 32, 24, 263, 251, 8)])
 def test_head_over_the_two_branch_outputs_matches_the_head_over_their_concatenation(pkg, n, ca, cb, h, w, classes):

@@ -97,6 +97,8 @@ SIGNATURES = {
     "ur_maxpool2x2_bwd_bnsums_supported": (_i, [_i, _i, _i, _i, _i]),
     "ur_maxpool2x2_bwd_bnsums": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ur_bn_bwd_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "ur_bn_act_fwd_pool_supported": (_i, [_i, _i, _i, _i, _i]),
+    "ur_bn_act_fwd_pool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ur_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _ll, _i, _i, _vp]),
     "ur_maxpool2x2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -388,6 +388,63 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __r
     }
 }
 
+// bn_act_fwd_bf16x8_kernel and MaxPool2d(2, 2) of its result in one pass: a thread owns 8 channels of one 2x2 window --
+// four 16-byte loads of y, four stores of z (possibly into a channel window), one store of the maximum and of the
+// 8 position bytes.  z is bit for bit what the plain kernel writes (same expression) and the maximum is taken over the
+// rounded values (first maximum in (ky, kx) order wins, NaN propagates: maxpool_fwd_kernel's rule), so the pooled tensor
+// and the positions equal those of the separate pooling pass, which would have to read z back.
+// C / 8 divides the grid stride (a power of two up to NT): a thread keeps its channels.
+__global__ __launch_bounds__(NT) void bn_act_fwd_pool_bf16x8_kernel(const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    int act, bf16_t* __restrict__ z, int z_ld,
+                                                                    bf16_t* __restrict__ pooled, uint8_t* __restrict__ idx, int N,
+                                                                    int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2, CV = C / 8;
+    const unsigned total = (unsigned)N * OH * OW * CV;
+    unsigned i = blockIdx.x * (unsigned)NT + threadIdx.x;
+    const int cv = (int)(i % CV);
+    Chan8 k;
+    k.load(mean, invstd, gamma, beta, cv * 8);
+    for (; i < total; i += gridDim.x * (unsigned)NT) {
+        const unsigned pix = i / CV;
+        const int ox = (int)(pix % OW);
+        const unsigned t = pix / OW;
+        const int oy = (int)(t % OH), n = (int)(t / OH);
+        const size_t p00 = ((size_t)n * H + 2 * oy) * W + 2 * ox;                 // pixel (2 oy, 2 ox)
+        const size_t poff[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+        bf16x8_t y8[4], o8[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y8[q] = ld_stream(y + poff[q] * C + cv * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                float o = ((float)y8[q][v] - k.m[v]) * k.is[v] * k.ga[v] + k.be[v];
+                if (act) o = fmaxf(o, 0.f);
+                o8[q][v] = (bf16_t)o;
+            }
+            st_stream(z + poff[q] * z_ld + cv * 8, o8[q]);
+        }
+        bf16x8_t m8;
+        unsigned long long sel = 0;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            float m = (float)o8[0][v];
+            int sl = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const float c = (float)o8[q][v];
+                if (c > m || c != c) { m = c; sl = q; }
+            }
+            m8[v] = (bf16_t)m;
+            sel |= (unsigned long long)sl << (8 * v);
+        }
+        st_stream(pooled + (size_t)pix * C + cv * 8, m8);
+        *reinterpret_cast<unsigned long long*>(idx + (size_t)pix * C + cv * 8) = sel;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void bn_act_fwd_scalar_kernel(const T* __restrict__ y, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
@@ -803,6 +860,30 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
                                 (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c, z_ld);
     });
     return ur_check_launch("bn_act_fwd");
+}
+
+int ur_bn_act_fwd_pool_supported(int dtype, int n, int h, int w, int c) {
+    const int cv = c / 8;
+    return dtype == UR_BF16 && n > 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0 && c >= 8 && c % 8 == 0 && cv <= NT &&
+           (cv & (cv - 1)) == 0 && (long long)n * h * w * c < (1LL << 31);
+}
+
+int ur_bn_act_fwd_pool(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                       void* z, int z_ld, void* pooled, uint8_t* idx, int dtype, int n, int h, int w, int c, ur_stream_t s) {
+    UR_REQUIRE(y && mean && invstd && gamma && beta && z && pooled && idx, "bn_act_fwd_pool: null pointer");
+    UR_REQUIRE(ur_bn_act_fwd_pool_supported(dtype, n, h, w, c),
+               "bn_act_fwd_pool: needs bf16, even height and width, a power-of-two channel count in [8, %d]", NT * 8);
+    if (z_ld == 0) z_ld = c;
+    UR_REQUIRE(z_ld >= c && z_ld % 8 == 0, "bn_act_fwd_pool: output pitch %d must be a multiple of 8 >= %d", z_ld, c);
+    UR_REQUIRE((long long)n * h * w * z_ld < (1LL << 40), "bn_act_fwd_pool: output too large");
+    UR_REQUIRE(aligned16(y) && aligned16(z) && aligned16(pooled) && aligned16(mean) && aligned16(invstd) && aligned16(gamma) &&
+               aligned16(beta) && ((uintptr_t)idx % 8) == 0, "bn_act_fwd_pool: pointers must be 16-byte aligned (idx: 8)");
+    const long long items = (long long)n * (h / 2) * (w / 2) * (c / 8);
+    long long grid = (items + NT - 1) / NT;
+    if (grid > 256 * UR_EW_BLOCKS_PER_CU) grid = 256 * UR_EW_BLOCKS_PER_CU;
+    hipLaunchKernelGGL(bn_act_fwd_pool_bf16x8_kernel, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)y, mean,
+                       invstd, gamma, beta, act, (bf16_t*)z, z_ld, (bf16_t*)pooled, idx, n, h, w, c);
+    return ur_check_launch("bn_act_fwd_pool");
 }
 
 int ur_bn_act_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* invstd,

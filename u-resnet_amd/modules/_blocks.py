@@ -38,12 +38,13 @@ def act_layer(act, inplace=False, neg_slope=0.2, n_prelu=1):
     raise NotImplementedError('activation layer [%s] is not found' % act)
 
 
-def _cba(seq, x, i, out=None):
+def _cba(seq, x, i, out=None, pool=False):
     """Run seq[i] (conv), seq[i+1] (BN), seq[i+2] (activation) fused when the activation is ReLU.  `out`: optional
-    channel window for the result (honoured on the fused path only; callers compare data_ptr())."""
+    channel window for the result (honoured on the fused path only; callers compare data_ptr()).  pool: the caller
+    max-pools the result next (ops.bn_act)."""
     conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
     if type(act) in _ACT_CODES:
-        return conv_bn_act(x, conv, bn, _ACT_CODES[type(act)], out=out)
+        return conv_bn_act(x, conv, bn, _ACT_CODES[type(act)], out=out, pool=pool)
     return act(conv_bn_act(x, conv, bn, _lib.ACT_NONE))
 
 
@@ -166,11 +167,12 @@ class DoubleConv(hnn.Sequential):
             hnn.BatchNorm2d(out_channels),
             hnn.ReLU(inplace=True))
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, pool=False):
+        """out: optional channel window for the result; pool: the caller max-pools the result next (see _cba)."""
         x = ops.as_activation(x, act_dtype(x))
         if has_hooks(*self):
             return super().forward(x)
-        return _cba(self, _cba(self, x, 0), 3, out)
+        return _cba(self, _cba(self, x, 0), 3, out, pool)
 
 
 class Down(hnn.Sequential):
@@ -340,11 +342,12 @@ def add_unet_branch(m, in_channels, base_c, levels=4):
         setattr(m, 'down%d' % (i + 1), Down(base_c << i, base_c << (i + 1)))
 
 
-def _skip_into_cat(block, x, up, pooled=None):
+def _skip_into_cat(block, x, up, pooled=None, pool_next=False):
     """Run the encoder stage `block` (DoubleConv or Down) on x and return (skip, cat): when possible the stage's last
     BatchNorm+ReLU writes the skip tensor straight into the first channel window of the tensor that `up` will
     concatenate it into (cat, else None), which removes the copy of the skip half of torch.cat (S/C:119-124).
-    pooled: the Down stage's max-pool result when the caller has already computed it (_pool_and_skip)."""
+    pooled: the Down stage's max-pool result when the caller has already computed it (_pool_and_skip).
+    pool_next: the caller max-pools the skip tensor next (the following Down stage)."""
     down = isinstance(block, Down)
     dc = block[1] if down else block
     fused = (isinstance(dc, DoubleConv) and isinstance(up, Up) and not has_hooks(block, up, up.up, *dc)
@@ -363,7 +366,7 @@ def _skip_into_cat(block, x, up, pooled=None):
     dtype = act_dtype(x)
     cat = ops.empty_nhwc(n, c_skip + c_up, h, w, dtype, x.device)
     win = ops.alias_window(cat, 0, c_skip)
-    skip = dc(block[0](x) if pooled is None else pooled, out=win) if down else dc(x, out=win)
+    skip = dc(block[0](x) if pooled is None else pooled, out=win, pool=pool_next) if down else dc(x, out=win, pool=pool_next)
     if skip.data_ptr() != win.data_ptr():          # the block could not honour the window
         return skip, None
     return skip, cat
@@ -373,10 +376,14 @@ fuse_pool_skip = True       # False: separate max-pool and gradient add (A/B com
 fuse_residual_grad = True   # False: the two gradients of a residual block's input are summed by a separate add
 
 
+def _pools_with_skip(down):
+    return fuse_pool_skip and isinstance(down, Down) and not has_hooks(down, down[0])
+
+
 def _pool_and_skip(down, x):
     """(max-pooled x for the stage `down`, x for the skip connection).  Without hooks both come from one operator whose
     backward sums the two gradients of x inside the pooling kernel; otherwise (None, x)."""
-    if (fuse_pool_skip and isinstance(down, Down) and not has_hooks(down, down[0]) and x.is_cuda and x.dim() == 4
+    if (_pools_with_skip(down) and x.is_cuda and x.dim() == 4
             and x.dtype in (torch.float32, torch.bfloat16) and x.requires_grad and ops._channel_pitch(x)):
         return ops.maxpool2x2_skip(x)
     return None, x
@@ -384,13 +391,13 @@ def _pool_and_skip(down, x):
 
 def unet_branch_forward(m, x, out=None):
     """out: optional channel window for the branch's result (see Up.forward)."""
-    x1, c1 = _skip_into_cat(m.in_conv, x, m.up4)
+    x1, c1 = _skip_into_cat(m.in_conv, x, m.up4, pool_next=_pools_with_skip(m.down1))
     p1, x1 = _pool_and_skip(m.down1, x1)
-    x2, c2 = _skip_into_cat(m.down1, x1, m.up3, p1)
+    x2, c2 = _skip_into_cat(m.down1, x1, m.up3, p1, pool_next=_pools_with_skip(m.down2))
     p2, x2 = _pool_and_skip(m.down2, x2)
-    x3, c3 = _skip_into_cat(m.down2, x2, m.up2, p2)
+    x3, c3 = _skip_into_cat(m.down2, x2, m.up2, p2, pool_next=_pools_with_skip(m.down3))
     p3, x3 = _pool_and_skip(m.down3, x3)
-    x4, c4 = _skip_into_cat(m.down3, x3, m.up1, p3)
+    x4, c4 = _skip_into_cat(m.down3, x3, m.up1, p3, pool_next=_pools_with_skip(m.down4))
     p4, x4 = _pool_and_skip(m.down4, x4)
     x5 = m.down4(x4) if p4 is None else m.down4[1](p4)
     u = m.up1(x5, x4, c4)

@@ -873,7 +873,8 @@ class _BNRecord:
 
 class _BNAct(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, stats, running_mean, running_var, nbt, training, momentum, eps, act, out, rec):
+    def forward(ctx, y, gamma, beta, residual, stats, running_mean, running_var, nbt, training, momentum, eps, act, out, rec,
+                pool=None):
         _require_gpu(y)
         n, c, h, w = y.shape
         rows = n * h * w
@@ -901,9 +902,19 @@ class _BNAct(Function):
             if tuple(z.shape) != tuple(y.shape) or z.dtype != y.dtype or not z_ld:
                 raise RuntimeError("bn_act: `out` must be a channel window with y's shape and dtype")
         tb = y.numel() * y.element_size()            # bytes of one pass over the tensor
-        with _Timed("hbm:bn_fwd", tb * (3 if residual is not None else 2)):
-            call("ur_bn_act_fwd", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                 _p(residual), act, z.data_ptr(), _dt(y), rows, c, z_ld, _stream())
+        if (pool is not None and residual is None and z_ld % 8 == 0 and z.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
+                and y.is_contiguous(memory_format=CL) and query("ur_bn_act_fwd_pool_supported", _dt(y), n, h, w, c)):
+            # the caller max-pools the result next (maxpool2x2_skip): both come out of one pass
+            pooled = empty_nhwc(n, c, h // 2, w // 2, y.dtype, dev)
+            idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=dev)
+            with _Timed("hbm:bn_fwd_pool", tb * 2 + pooled.numel() * (pooled.element_size() + 1)):
+                call("ur_bn_act_fwd_pool", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
+                     z.data_ptr(), z_ld, pooled.data_ptr(), idx.data_ptr(), _dt(y), n, h, w, c, _stream())
+            pool.append((pooled, idx))
+        else:
+            with _Timed("hbm:bn_fwd", tb * (3 if residual is not None else 2)):
+                call("ur_bn_act_fwd", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                     _p(residual), act, z.data_ptr(), _dt(y), rows, c, z_ld, _stream())
         # the ReLU mask is recomputed from y in backward unless a residual was added before the activation
         ctx.save_for_backward(y, z if (act and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.act, ctx.eval, ctx.has_res = act, not training, residual is not None
@@ -958,25 +969,33 @@ class _BNAct(Function):
             call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
                  gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres),
                  _dt(y), rows, c, dz_ld, _stream())
-        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
-def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU, out=None):
+fuse_bn_pool = os.environ.get("URESNET_BN_POOL", "1") != "0"    # False: the max-pool after an encoder stage reads the stage's result back
+
+
+def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU, out=None, pool=False):
     """BatchNorm2d module `bn` applied to y, fused with an optional residual add and ReLU.  `out`: optional
-    channel window (alias_window) to write the result into."""
+    channel window (alias_window) to write the result into.  pool: the caller hands the result to maxpool2x2_skip next;
+    where the fused kernel covers the shape the pooled tensor is computed in the same pass and travels with the result
+    (attribute `_ur_pooled`)."""
     training = bn.training or bn.running_mean is None
     if training and bn.momentum is None:
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not implemented")
     track = training and bn.track_running_stats and bn.running_mean is not None
     rec = _BNRecord() if (fuse_bn_bwd_sums and training and torch.is_grad_enabled()) else None
+    hold = [] if (pool and fuse_bn_pool and residual is None and y.is_cuda and y.dim() == 4 and torch.is_grad_enabled()) else None
     z = _BNAct.apply(y, bn.weight, bn.bias, residual, stats if training else None,
                      bn.running_mean if (track or not training) else None,
                      bn.running_var if (track or not training) else None,
                      bn.num_batches_tracked if track else None,
                      training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, act,
-                     None if out is None else (out,), rec)
+                     None if out is None else (out,), rec, hold)
     if rec is not None and getattr(rec, "y", None) is not None:
         z._ur_bn = rec           # a following 3x3 convolution picks it up (see _BNRecord)
+    if hold:
+        z._ur_pooled = hold[0] + (z.data_ptr(), z._version)
     return z
 
 
@@ -1283,11 +1302,17 @@ class _MaxPool2x2Skip(Function):
     def forward(ctx, x):
         _require_gpu(x)
         n, c, h, w = x.shape
-        y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
-        idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
-        with _Timed("hbm:maxpool_fwd", x.numel() * x.element_size() + y.numel() * (y.element_size() + 1)):
-            call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _channel_pitch(x) or c,
-                 _stream())
+        pre = getattr(x, "_ur_pooled", None)
+        if pre is not None:
+            x._ur_pooled = None
+        if pre is not None and pre[2] == x.data_ptr() and pre[3] == x._version and tuple(pre[0].shape) == (n, c, h // 2, w // 2):
+            y, idx = pre[0], pre[1]                  # the BatchNorm pass that wrote x pooled it too (bn_act(pool=True))
+        else:
+            y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
+            idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
+            with _Timed("hbm:maxpool_fwd", x.numel() * x.element_size() + y.numel() * (y.element_size() + 1)):
+                call("ur_maxpool2x2_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), _dt(x), n, h, w, c, _channel_pitch(x) or c,
+                     _stream())
         ctx.save_for_backward(idx)
         ctx.shape = (n, c, h, w)
         ctx.bn_rec = getattr(x, "_ur_bn", None)      # x is a BatchNorm+ReLU output: its backward sums can come from here
