@@ -410,19 +410,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
             bs1[k] = 0.f; bs2[k] = 0.f;
         }
     }
+    // Piece i of a lane (i = 0 .. 4R-1) is pixel (row i >> 2, column 8 (i & 3) + (lane >> 3)) of the wave's rows, channels
+    // 8 (lane & 7) .. +8: its element offset in a tensor of pitch ld is a per-lane base plus (i >> 2) W ld + (i & 3) 8 ld,
+    // two uniform terms with compile-time factors (all tensors hold fewer than 2^31 elements: checked on the host).  Written
+    // out per piece as (pixel index) * pitch, the epilogue spent ~190 quarter-rate multiplies per lane on addresses.
+    const int pix_lane = (img * p.H + ty0 + wave * R) * p.W + tx0 + (lane >> 3);
+    const int ch_lane = nb * BN + (lane & 7) * 8;
+    struct Base { int at, ld; };        // element offset of the lane's piece 0 in one tensor, and the tensor's pitch
+    auto base_of = [&](int ld) { return Base{pix_lane * ld + ch_lane, ld}; };
+    const Base b_out = base_of(p.ld_out), b_bny = base_of(EPI >= 3 ? p.ld_bny : 0), b_z = base_of(EPI >= 5 ? p.Cout : 0),
+               b_add = base_of(p.ld_add);
+    auto elem_off = [&](int i, const Base& b) { return b.at + ((i >> 2) * p.W + (i & 3) * 8) * b.ld; };
     auto store_piece = [&](int i, bool check) {
         const int idx = lane + 64 * i;
         const int pxl = idx >> 3, piece = idx & 7;
         const int oy = ty0 + wave * R + (pxl >> 5), ox = tx0 + (pxl & 31);
         if (!check || (oy < p.H && ox < p.W && nb * BN + piece * 8 < p.Cout)) {
-            const size_t pix = (size_t)(img * p.H + oy) * p.W + ox;
             bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ostage + pxl * OUT_PITCH + piece * 16);
             if constexpr (BNSUMS) {
-                const bf16x8_t y8 = Y_LOAD(reinterpret_cast<const bf16x8_t*>(p.bn_y + pix * p.ld_bny + nb * BN + piece * 8));
+                const bf16x8_t y8 = Y_LOAD(reinterpret_cast<const bf16x8_t*>(p.bn_y + elem_off(i, b_bny)));
                 bf16x8_t z8 = y8;
-                if constexpr (BN_FROM_Z) z8 = *reinterpret_cast<const bf16x8_t*>(p.bn_z + pix * p.Cout + nb * BN + piece * 8);
+                if constexpr (BN_FROM_Z) z8 = *reinterpret_cast<const bf16x8_t*>(p.bn_z + elem_off(i, b_z));
                 if constexpr (BN_ADD) {
-                    const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
+                    const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(p.addend + elem_off(i, b_add));
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = (bf16_t)((float)v[k] + (float)ad[k]);
                 }
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
             }
             if constexpr (EPI == 1 || EPI == 2) {
                 if (EPI == 1 || p.addend) {
-                    const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
+                    const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(p.addend + elem_off(i, b_add));
                     const bool relu = EPI == 2 && p.relu;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
                     }
                 }
             }
-            OUT_STORE(reinterpret_cast<bf16x8_t*>(p.y + pix * p.ld_out + nb * BN + piece * 8), v);
+            OUT_STORE(reinterpret_cast<bf16x8_t*>(p.y + elem_off(i, b_out)), v);
         }
     };
     if (interior && (nb + 1) * BN <= p.Cout) {
@@ -460,17 +470,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
                 bf16x8_t yv[BT], zv[BT], av[BT];
 #pragma unroll
                 for (int j = 0; j < BT; ++j) {
-                    const int idx = lane + 64 * (b0 + j), pxl = idx >> 3, piece = idx & 7;
-                    const size_t pix = (size_t)(img * p.H + ty0 + wave * R + (pxl >> 5)) * p.W + tx0 + (pxl & 31);
-                    yv[j] = Y_LOAD(reinterpret_cast<const bf16x8_t*>(p.bn_y + pix * p.ld_bny + nb * BN + piece * 8));
-                    if constexpr (BN_FROM_Z) zv[j] = *reinterpret_cast<const bf16x8_t*>(p.bn_z + pix * p.Cout + nb * BN + piece * 8);
-                    if constexpr (BN_ADD) av[j] = *reinterpret_cast<const bf16x8_t*>(p.addend + pix * p.ld_add + nb * BN + piece * 8);
+                    yv[j] = Y_LOAD(reinterpret_cast<const bf16x8_t*>(p.bn_y + elem_off(b0 + j, b_bny)));
+                    if constexpr (BN_FROM_Z) zv[j] = *reinterpret_cast<const bf16x8_t*>(p.bn_z + elem_off(b0 + j, b_z));
+                    if constexpr (BN_ADD) av[j] = *reinterpret_cast<const bf16x8_t*>(p.addend + elem_off(b0 + j, b_add));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < BT; ++j) {
                     const int idx = lane + 64 * (b0 + j), pxl = idx >> 3, piece = idx & 7;
-                    const size_t pix = (size_t)(img * p.H + ty0 + wave * R + (pxl >> 5)) * p.W + tx0 + (pxl & 31);
                     bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ostage + pxl * OUT_PITCH + piece * 16);
                     if constexpr (BN_ADD) {
 #pragma unroll
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
                         const float gv = pre > 0.f ? (float)v[k] : 0.f;
                         bs1[k] += gv; bs2[k] += gv * xh;
                     }
-                    OUT_STORE(reinterpret_cast<bf16x8_t*>(p.y + pix * p.ld_out + nb * BN + piece * 8), v);
+                    OUT_STORE(reinterpret_cast<bf16x8_t*>(p.y + elem_off(b0 + j, b_out)), v);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
