@@ -268,6 +268,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
         int t = tid;
         asm volatile("" : "+v"(t));
         Walk wk; wk.start(t);
+        // Last slice of a launch that also sums a BatchNorm's backward terms: the halo registers are free from here on, so
+        // the first NW of the lane's 4R pieces of that BatchNorm's input are fetched into them now, under this slice's MFMAs,
+        // instead of after the main loop where nothing overlaps the read.  Tiles that the epilogue handles piece by piece
+        // (image border, half-empty channel block) fetch element 0 instead and load their pieces there as before.
+        constexpr bool YPRE = !NEXT && EPI >= 3 && EPI <= 6;
+        int ybase = 0, yrow = 0, ycol = 0;
+        if constexpr (YPRE) {
+            const bool whole = ty0 + G::TH <= p.H && tx0 + TW <= p.W && (nb + 1) * BN <= p.Cout;
+            const int l = t & 63, wv = t >> 6;
+            ybase = whole ? ((img * p.H + ty0 + wv * R) * p.W + tx0 + (l >> 3)) * p.ld_bny + nb * BN + (l & 7) * 8 : 0;
+            yrow = whole ? p.W * p.ld_bny : 0;
+            ycol = whole ? 8 * p.ld_bny : 0;
+        }
         const unsigned ab[3] = {a_base[0] + so, a_base[1] + so, a_base[2] + so};
         const unsigned bb = b_base + so;
         bf16x8_t ar[4], br[8];
@@ -296,6 +309,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
                 if constexpr (!ODD && PAIR) load_piece(ph[P - S::WS], wk, t, chunk + 2);
                 wk.next();
             }
+            if constexpr (YPRE && P >= S::WS && P < S::WS + NW && P - S::WS < 4 * R) {
+                constexpr int j = P - S::WS;
+                ph[j] = Y_LOAD(reinterpret_cast<const bf16x8_t*>(p.bn_y + ybase + (j >> 2) * yrow + (j & 3) * ycol));
+            }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int a = i - dy;
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
         });
         // this wave's LDS-DMA pieces and halo writes have landed (the halo loads just issued stay in flight)
         if constexpr (!ODD && PAIR) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NW) : "memory");
+        else if constexpr (YPRE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fetches above stay in flight
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
@@ -470,7 +488,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_tile_kernel(TileParams p)
                 bf16x8_t yv[BT], zv[BT], av[BT];
 #pragma unroll
                 for (int j = 0; j < BT; ++j) {
-                    yv[j] = Y_LOAD(reinterpret_cast<const bf16x8_t*>(p.bn_y + elem_off(b0 + j, b_bny)));
+                    if (b0 + j < NW) yv[j] = ph[b0 + j];          // fetched during the last slice
+                    else yv[j] = Y_LOAD(reinterpret_cast<const bf16x8_t*>(p.bn_y + elem_off(b0 + j, b_bny)));
                     if constexpr (BN_FROM_Z) zv[j] = *reinterpret_cast<const bf16x8_t*>(p.bn_z + elem_off(b0 + j, b_z));
                     if constexpr (BN_ADD) av[j] = *reinterpret_cast<const bf16x8_t*>(p.addend + elem_off(b0 + j, b_add));
                 }
