@@ -260,7 +260,10 @@ def test_fused_paths_randomised_against_separate_passes(pkg, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 64, 8, 16, 32), (1, 128, 5, 7, 64), (2, 16, 4, 4, 8)])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 16, 32), (1, 128, 5, 7, 64), (2, 16, 4, 4, 8),
+                                   # wide enough for the DMA-staged row GEMM: a row tile that ends inside the tensor, a width
+                                   # that is not a power of two, rows of a wave that wrap to the next image row
+                                   (1, 128, 6, 64, 64), (2, 128, 5, 96, 64), (1, 256, 3, 70, 128)])
 def test_conv_transpose2x2(pkg, shape, dtype):
     n, cin, h, w, cout = shape
     g = torch.Generator().manual_seed(3)
@@ -281,6 +284,46 @@ def test_conv_transpose2x2(pkg, shape, dtype):
     assert rel_l2(xd.grad.cpu(), xr.grad) < tol
     assert rel_l2(wd.grad.cpu(), wr.grad) < tol
     assert rel_l2(bd.grad.cpu(), br.grad) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,h,w,cout", [(1, 128, 6, 64, 64), (2, 128, 5, 96, 64), (1, 256, 3, 70, 128), (2, 512, 8, 64, 256)])
+def test_transposed_convolution_row_gemm_equals_the_gather_kernel_bit_for_bit(pkg, n, cin, h, w, cout, monkeypatch):
+    """ConvTranspose2d(2, 2) (S/C:113) through the DMA-staged row GEMM (convt_gemm.hip) against the generic gather kernel
+    (URESNET_CONVT_GEMM=0) through the same entry points: forward into a dense tensor and into the second channel window
+    of a concatenated tensor (whose other half must stay untouched), backward-data from a dense gradient and from the
+    window of a concatenated gradient -- the same products in the same order, so every bit agrees."""
+    import ctypes as C
+    L = pkg._lib
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t, off=0: C.c_void_p(t.data_ptr() + off)  # noqa: E731
+    g = torch.Generator().manual_seed(n + cin + w)
+    x = torch.randn(n, h, w, cin, generator=g).to(DEV).to(torch.bfloat16)
+    wt = (torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5).to(DEV)
+    bias = torch.randn(cout, generator=g).to(DEV)
+    for window in (False, True):
+        ld = 2 * cout if window else cout
+        off = cout * 2 if window else 0                                   # byte offset of the window's first channel
+        d = L.ConvDesc(L.UR_BF16, n, h, w, cin, 2 * h, 2 * w, cout, 2, 2, 2, 0, cin, ld)
+        dy = torch.randn(n, 2 * h, 2 * w, ld, generator=g).to(DEV).to(torch.bfloat16)
+        wf = torch.empty(L.query("ur_conv2d_packed_elems", C.byref(d), L.PACK_CONVT_FWD), dtype=torch.bfloat16, device=DEV)
+        wd = torch.empty(L.query("ur_conv2d_packed_elems", C.byref(d), L.PACK_CONVT_DGRAD), dtype=torch.bfloat16, device=DEV)
+        L.call("ur_conv2d_pack_weight", vp(wt), vp(wf), C.byref(d), L.PACK_CONVT_FWD, st)
+        L.call("ur_conv2d_pack_weight", vp(wt), vp(wd), C.byref(d), L.PACK_CONVT_DGRAD, st)
+        res = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("URESNET_CONVT_GEMM", flag)
+            y = torch.full((n, 2 * h, 2 * w, ld), 3.0, dtype=torch.bfloat16, device=DEV)
+            dx = torch.empty(n, h, w, cin, dtype=torch.bfloat16, device=DEV)
+            L.call("ur_convT2x2_fwd", vp(x), vp(wf), vp(bias), vp(y, off), C.byref(d), st)
+            L.call("ur_convT2x2_dgrad", vp(dy, off), vp(wd), vp(dx), C.byref(d), st)
+            torch.cuda.synchronize()
+            res.append((y, dx))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        if window:
+            assert bool((res[1][0][..., :cout] == 3.0).all())
+        ref = F.conv_transpose2d(x.float().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), bias, stride=2).permute(0, 2, 3, 1)
+        assert rel_l2(res[1][0][..., off // 2:off // 2 + cout].float().cpu(), ref.cpu()) < 5e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

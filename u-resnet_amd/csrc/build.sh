@@ -7,7 +7,7 @@ OBJ="$HERE/../lib/obj"
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${URESNET_EXTRA_FLAGS:-}"
-SRCS=(common conv_igemm conv1x1_pw conv1x1_pw_wgrad conv3x3_tile conv3x3_wide wgrad3x3_tile conv_wgrad conv_group bn spatial loss optim)
+SRCS=(common conv_igemm convt_gemm conv1x1_pw conv1x1_pw_wgrad conv3x3_tile conv3x3_wide wgrad3x3_tile conv_wgrad conv_group bn spatial loss optim)
 pids=()
 for s in "${SRCS[@]}"; do
     src="$HERE/$s.hip"

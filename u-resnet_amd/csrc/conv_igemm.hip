@@ -586,6 +586,12 @@ int ur_conv2d_dgrad(const void* dy, const void* wp, void* dx, const ur_conv_desc
     UR_DISPATCH_DTYPE(d->dtype, return dispatch_igemm<T>(p, (hipStream_t)s));
 }
 
+// URESNET_CONVT_GEMM=0: the transposed convolutions stay on the gather kernel (A/B runs)
+static bool convt_gemm_enabled() {
+    const char* e = getenv("URESNET_CONVT_GEMM");          // read per call: tests switch it inside one process
+    return !e || e[0] != '0';
+}
+
 static int check_convT(const ur_conv_desc* d) {
     if (int e = check_desc(d)) return e;
     UR_REQUIRE(d->kh == 2 && d->kw == 2 && d->stride == 2 && d->pad == 0, "convT2x2: kernel must be 2x2 stride 2 pad 0");
@@ -596,6 +602,7 @@ static int check_convT(const ur_conv_desc* d) {
 int ur_convT2x2_fwd(const void* x, const void* wp, const float* bias, void* y, const ur_conv_desc* d, ur_stream_t s) {
     if (int e = check_convT(d)) return e;
     UR_REQUIRE(x && wp && y, "convT2x2_fwd: null pointer");
+    if (convt_gemm_enabled() && ur_convt_gemm_supported(d, 0, x, y)) return ur_convt_gemm_fwd(x, wp, bias, y, d, (hipStream_t)s);
     IgemmParams p{};
     p.src = x; p.wgt = wp; p.bias = bias; p.dst = y;
     p.N = d->n; p.H = d->h; p.W = d->w; p.C = d->cin;
@@ -610,6 +617,7 @@ int ur_convT2x2_fwd(const void* x, const void* wp, const float* bias, void* y, c
 int ur_convT2x2_dgrad(const void* dy, const void* wp, void* dx, const ur_conv_desc* d, ur_stream_t s) {
     if (int e = check_convT(d)) return e;
     UR_REQUIRE(dy && wp && dx, "convT2x2_dgrad: null pointer");
+    if (convt_gemm_enabled() && ur_convt_gemm_supported(d, 1, dx, dy)) return ur_convt_gemm_dgrad(dy, wp, dx, d, (hipStream_t)s);
     IgemmParams p{};                                          // a forward 2x2 stride-2 conv over dy
     p.src = dy; p.wgt = wp; p.dst = dx;
     p.N = d->n; p.H = d->oh; p.W = d->ow; p.C = d->cout;

@@ -20,6 +20,12 @@ int ur_check_launch(const char* what);
 // fragment-order image of a 3x3 layer's weights for the tile kernel (wide = 0) or the 128-channel kernel (wide = 1)
 int ur_pack3x3_image(const float* w, void* packed, int cin, int cout, int dgrad, int wide, hipStream_t s);
 
+// ConvTranspose2d(2, 2) forward / backward-data as a DMA-staged row GEMM (convt_gemm.hip); `supported` says whether a launch
+// can go there (x: the low-resolution tensor, y: the 2x tensor), else the callers use the gather kernel
+int ur_convt_gemm_supported(const ur_conv_desc* d, int dgrad, const void* x, const void* y);
+int ur_convt_gemm_fwd(const void* x, const void* wp, const float* bias, void* y, const ur_conv_desc* d, hipStream_t st);
+int ur_convt_gemm_dgrad(const void* dy, const void* wp, void* dx, const ur_conv_desc* d, hipStream_t st);
+
 #define UR_REQUIRE(cond, ...)                 \
     do {                                      \
         if (!(cond)) {                        \
