@@ -52,13 +52,21 @@ def main():
         dx = torch.empty(n, h, w, cin, dtype=torch.bfloat16, device=dev)
         f = lambda: lib.ur_convT2x2_fwd(vp(x), vp(wf), vp(bias), vp(y), C.byref(d), st)  # noqa: E731
         g = lambda: lib.ur_convT2x2_dgrad(vp(dy), vp(wd), vp(dx), C.byref(d), st)  # noqa: E731
-        assert f() == 0 and g() == 0
+        lib.ur_convT2x2_wgrad_workspace.restype = C.c_size_t
+        ws = torch.empty(lib.ur_convT2x2_wgrad_workspace(C.byref(d)), dtype=torch.uint8, device=dev)
+        dw = torch.empty(cin, cout, 2, 2, device=dev)
+        wg = lambda: lib.ur_convT2x2_wgrad(vp(x), vp(dy), vp(dw), vp(ws), C.c_size_t(ws.numel()), C.byref(d), st)  # noqa: E731
+        assert f() == 0 and g() == 0 and wg() == 0
         torch.cuda.synchronize()
         ref = torch.nn.functional.conv_transpose2d(x.float().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), bias, stride=2)
         err = ((y.float().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item()
-        tf, tg = timed(f), timed(g)
-        print("%-26s fwd %7.1f us %6.0f TF (err %.1e)   dgrad %7.1f us %6.0f TF" % (
-            (n, h, w, cin, cout), tf * 1e3, flops / tf / 1e9, err, tg * 1e3, flops / tg / 1e9), flush=True)
+        refw = torch.einsum("nyxi,nyxqo->ioq", x.float(), dy.float().view(n, h, 2, w, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(
+            n, h, w, 4, cout)).reshape(cin, cout, 2, 2)
+        errw = ((dw - refw).norm() / refw.norm()).item()
+        tf, tg, tw = timed(f), timed(g), timed(wg)
+        print("%-26s fwd %7.1f us %6.0f TF (err %.1e)   dgrad %7.1f us %6.0f TF   wgrad %7.1f us %6.0f TF (err %.1e)" % (
+            (n, h, w, cin, cout), tf * 1e3, flops / tf / 1e9, err, tg * 1e3, flops / tg / 1e9, tw * 1e3, flops / tw / 1e9, errw),
+            flush=True)
 
 
 if __name__ == "__main__":

@@ -30,6 +30,7 @@ struct WgradParams {
     int u_ld, dv_ld;
     int stages_per_split;
     int ntiles;
+    int xcd_order;       // splits are a multiple of 8: see the kernel's id decoding
 };
 
 template <typename T> struct WgCfg;
@@ -62,7 +63,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) T As[BK * PITCH];
     __shared__ __attribute__((aligned(16))) T Bs[BK * PITCH];
 
-    const int tile = blockIdx.x, split = blockIdx.y;
+    // Workgroup ids congruent mod 8 run on one XCD (one L2 each).  With xcd_order all output tiles of a pixel range (split)
+    // go to one XCD, next to each other in dispatch order, so the operand rows that those tiles share are fetched from memory
+    // once and not once per tile (a transposed convolution 256 -> 128 has 8 tiles: 800 MB of operand reads for 300 MB).
+    int tile = blockIdx.x, split = blockIdx.y;
+    if (p.xcd_order) {
+        const int id = blockIdx.x + gridDim.x * blockIdx.y, j = id >> 3;
+        tile = j % (int)gridDim.x;
+        split = (j / (int)gridDim.x) * 8 + (id & 7);
+    }
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int o0 = mt * TM, n0 = nt * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -303,6 +312,8 @@ int launch_wgrad(WgradParams& p, float* dw, hipStream_t st) {
     WgradPlan pl = plan_for<T>(p.O, p.Kred, p.P);
     p.stages_per_split = pl.stages_per_split;
     p.ntiles = pl.ntiles;
+    static const bool xcd_ok = [] { const char* e = getenv("URESNET_WGRAD_XCD"); return !e || e[0] != '0'; }();
+    p.xcd_order = xcd_ok && pl.nsplit % 8 == 0 && pl.mtiles * pl.ntiles > 1;
     dim3 grid(pl.mtiles * pl.ntiles, pl.nsplit);
     constexpr int VW = WgCfg<T>::VW;
     const bool va = (p.O % VW == 0) && (p.dv_ld % VW == 0) && ((uintptr_t)p.dv % 16 == 0);
