@@ -16,7 +16,8 @@ the step (kernels that do one job -- e.g. the two 3x3 forward / backward-data ke
 epilogue variants -- count as one family), timed live with events on the stream each launch runs on:
 the top-level numbers are those of the timed region's own streams, `isolated_one_stream` repeats them
 with every kernel alone on the chip, `matrix_pipe_utilisation_of_the_step` divides all convolution
-FLOPs by the wall time.  `cpu_baseline` is the oracle (plain PyTorch fp32 restatement of the reference)
+FLOPs by the wall time, `against_the_lower_of_both_roofs` prices every launch of the family against
+max(FLOPs / matrix-core peak, operand bytes / HBM peak).  `cpu_baseline` is the oracle (plain PyTorch fp32 restatement of the reference)
 on the host cores.
 
 A rank that hangs does not sit until the caller's limit: with more than one rank every process arms a
@@ -438,6 +439,26 @@ def main():
                                    "frac": round(kernels[t_][1] / kernels[t_][2] / 1e12 / peak, 4),
                                    "avg_launch_ms": round(kernels[t_][2] / kernels[t_][0] * 1e3, 4)}
                               for t_ in fam["tags"] if t_ in kernels}
+            # The family against the LOWER of its two roofs, launch by launch: a 3x3 layer with 64 channels moves a byte per
+            # 185-275 FLOP, so at 8 TB/s its memory roof lies below the matrix-core peak.  roof time of a launch =
+            # max(FLOPs / peak, operand bytes / HBM peak), operands = activations in and out once, the weight image once and,
+            # for the launches that also sum a BatchNorm's backward terms, that BatchNorm's input once.
+            roof_sec = meas_sec = hbm_side_sec = 0.0
+            for (tag, shp), (cnt, fl, sec) in shapes.items():
+                if tag in fam["tags"] and shp:
+                    n_, h_, w_, ci, co, k_, _s = shp
+                    produced = ci if "dgrad" in tag else co
+                    by = (n_ * h_ * w_ * (ci + co + (produced if tag.endswith("_bn") else 0)) + ci * co * k_ * k_) * esz
+                    t_m, t_h = fl / cnt / (peak * 1e12), by / (HBM_PEAK_GBS * 1e9)
+                    roof_sec += cnt * max(t_m, t_h)
+                    meas_sec += sec
+                    hbm_side_sec += sec if t_h > t_m else 0.0
+            if meas_sec > 0:
+                roof["against_the_lower_of_both_roofs"] = {
+                    "frac": round(roof_sec / meas_sec, 4),
+                    "time_share_of_launches_whose_memory_roof_is_the_lower": round(hbm_side_sec / meas_sec, 3),
+                    "note": "sum over the family's launches of max(FLOPs / %.0f TFLOP/s, operand bytes / %.0f GB/s) divided by their "
+                            "measured time (%s)" % (peak, HBM_PEAK_GBS, "one-stream pass" if isolated_timings is not None else "timed region")}
             roof["other_families"] = {FAMILIES[k]["kernel"]: v for k, v in iso.items() if k != dominant}
             if region_kernels and isolated_timings is not None:
                 roof["other_families_in_timed_region"] = {
