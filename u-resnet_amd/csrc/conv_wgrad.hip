@@ -57,8 +57,11 @@ template <typename T> struct Chunk<T, 1> {
     __device__ __forceinline__ void store(T* p) const { *p = v; }
 };
 
-template <typename T, int VA, int VB>
+// TMT = rows (channels of dV) of the output tile: 128 (2 x 2 waves of 64 x 64) or 64 (1 x 4 waves of 64 x 32) for layers
+// with at most 64 such channels, which would leave half of every 128-row tile's MFMAs multiplying zeros.
+template <typename T, int VA, int VB, int TMT>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int WN = TMT == 128 ? 2 : 4, WCOLS = TN / WN, NBL = WCOLS / 32;      // waves along n, columns and 32-blocks per wave
     constexpr int BK = WgCfg<T>::BK, PITCH = WgCfg<T>::PITCH;
     __shared__ __attribute__((aligned(16))) T As[BK * PITCH];
     __shared__ __attribute__((aligned(16))) T Bs[BK * PITCH];
@@ -73,14 +76,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
         split = (j / (int)gridDim.x) * 8 + (id & 7);
     }
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    const int o0 = mt * TM, n0 = nt * TN;
+    const int o0 = mt * TMT, n0 = nt * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;           // 2x2 waves, 64x64 each
+    const int wm = wave / WN, wn = wave % WN;
     const T* __restrict__ U = static_cast<const T*>(p.u);
     const T* __restrict__ DV = static_cast<const T*>(p.dv);
 
-    // loader geometry: chunks of V channels; (TM/V) chunk-columns per pixel row
-    constexpr int ACOLS = TM / VA, AROWS_PER_PASS = NTHREADS / ACOLS, APASS = BK / AROWS_PER_PASS;
+    // loader geometry: chunks of V channels; (TMT/V) chunk-columns per pixel row
+    constexpr int ACOLS = TMT / VA, AROWS_PER_PASS = NTHREADS / ACOLS, APASS = BK / AROWS_PER_PASS;
     constexpr int BCOLS = TN / VB, BROWS_PER_PASS = NTHREADS / BCOLS, BPASS = BK / BROWS_PER_PASS;
     const int a_col = (tid % ACOLS) * VA, a_row = tid / ACOLS;
     const int b_col = (tid % BCOLS) * VB, b_row = tid / BCOLS;
@@ -164,11 +167,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
         for (int i = 0; i < BPASS; ++i) pb[i].store(&Bs[(b_row + i * BROWS_PER_PASS) * PITCH + b_col]);
     };
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[2][NBL];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NBL; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
             const int t_pix = 8 * (g >> 1) + (li >> 2), t_ch = 16 * (g & 1) + 4 * (li & 3);
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8_t af[2], bfr[2];
+                bf16x8_t af[2], bfr[NBL];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const T* q = &As[(ks * 16 + t_pix) * PITCH + wm * 64 + a * 32 + t_ch];
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
                     af[a] = __builtin_bit_cast(bf16x8_t, both);
                 }
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const T* q = &Bs[(ks * 16 + t_pix) * PITCH + wn * 64 + b * 32 + t_ch];
+                for (int b = 0; b < NBL; ++b) {
+                    const T* q = &Bs[(ks * 16 + t_pix) * PITCH + wn * WCOLS + b * 32 + t_ch];
                     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)q);
                     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + 4 * PITCH));
                     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -207,22 +210,22 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < NBL; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
             }
         } else {
             const int lrow = lane & 31, lhalf = lane >> 5;
 #pragma unroll 4
             for (int kk = 0; kk < BK; kk += 2) {
-                float af[2], bfr[2];
+                float af[2], bfr[NBL];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) af[a] = As[(kk + lhalf) * PITCH + wm * 64 + a * 32 + lrow];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) bfr[b] = Bs[(kk + lhalf) * PITCH + wn * 64 + b * 32 + lrow];
+                for (int b = 0; b < NBL; ++b) bfr[b] = Bs[(kk + lhalf) * PITCH + wn * WCOLS + b * 32 + lrow];
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < NBL; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
             }
         }
@@ -234,8 +237,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int n = n0 + wn * 64 + b * 32 + lrow;
+        for (int b = 0; b < NBL; ++b) {
+            const int n = n0 + wn * WCOLS + b * 32 + lrow;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
@@ -281,13 +284,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
     dw[((long long)o * I + i) * taps + tap] = t;
 }
 
-struct WgradPlan { int mtiles, ntiles, nsplit, stages_per_split; };
+struct WgradPlan { int mtiles, ntiles, nsplit, stages_per_split, tm; };
 
 template <typename T>
 WgradPlan plan_for(int O, int Kred, long long P) {
     constexpr int BK = WgCfg<T>::BK;
     WgradPlan pl;
-    pl.mtiles = ur_cdiv(O, TM);
+    static const bool tm64 = [] { const char* e = getenv("URESNET_WGRAD_TM64"); return !e || e[0] != '0'; }();   // 0: A/B runs
+    pl.tm = (O <= 64 && tm64) ? 64 : TM;
+    pl.mtiles = ur_cdiv(O, pl.tm);
     pl.ntiles = ur_cdiv(Kred, TN);
     long long stages = (P + BK - 1) / BK;
     long long tiles = (long long)pl.mtiles * pl.ntiles;
@@ -318,10 +323,16 @@ int launch_wgrad(WgradParams& p, float* dw, hipStream_t st) {
     constexpr int VW = WgCfg<T>::VW;
     const bool va = (p.O % VW == 0) && (p.dv_ld % VW == 0) && ((uintptr_t)p.dv % 16 == 0);
     const bool vb = (p.I % VW == 0) && (p.u_ld % VW == 0) && ((uintptr_t)p.u % 16 == 0);
-    if (va && vb) hipLaunchKernelGGL((conv_wgrad_kernel<T, VW, VW>), grid, dim3(NTHREADS), 0, st, p);
-    else if (va) hipLaunchKernelGGL((conv_wgrad_kernel<T, VW, 1>), grid, dim3(NTHREADS), 0, st, p);
-    else if (vb) hipLaunchKernelGGL((conv_wgrad_kernel<T, 1, VW>), grid, dim3(NTHREADS), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 1, 1>), grid, dim3(NTHREADS), 0, st, p);
+#define UR_WGRAD_LAUNCH(A_, B_)                                                                                         \
+    do {                                                                                                                \
+        if (pl.tm == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, A_, B_, 64>), grid, dim3(NTHREADS), 0, st, p);        \
+        else hipLaunchKernelGGL((conv_wgrad_kernel<T, A_, B_, 128>), grid, dim3(NTHREADS), 0, st, p);                   \
+    } while (0)
+    if (va && vb) UR_WGRAD_LAUNCH(VW, VW);
+    else if (va) UR_WGRAD_LAUNCH(VW, 1);
+    else if (vb) UR_WGRAD_LAUNCH(1, VW);
+    else UR_WGRAD_LAUNCH(1, 1);
+#undef UR_WGRAD_LAUNCH
     if (int e = ur_check_launch("conv_wgrad")) return e;
     const long long per = (long long)p.O * p.Kred;
     if (per % 4 != 0)
