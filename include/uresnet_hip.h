@@ -369,6 +369,15 @@ int ur_ce_fwd(const void* logits, int dtype, const int64_t* target, long long ro
 int ur_ce_bwd(const void* logits, int dtype, const int64_t* target, long long rows, int classes, int ld,
               long long ignore_index, const float* lse, const float* count, const float* gout, void* dlogits,
               int dld, ur_stream_t s);
+/* ur_ce_bwd for the 1x1 head behind the loss (S/C:127-133 -> train_UResNetAblitionStudy.py:62-68): the gradient rows are
+ * written `dld` columns wide (>= classes, zero fill; dld * element size a multiple of 16 and at most 64 bytes) -- the form
+ * the streaming 1x1 kernels read -- and colsum[classes] receives the per-class sums of the stored gradient, which is that
+ * head's bias gradient.  Saves a pass that widens the rows and a pass that sums them. */
+size_t ur_ce_bwd_padded_workspace(long long rows);
+int ur_ce_bwd_padded_supported(int dtype, int classes, int dld);
+int ur_ce_bwd_padded(const void* logits, int dtype, const int64_t* target, long long rows, int classes,
+                     long long ignore_index, const float* lse, const float* count, const float* gout, void* dlogits, int dld,
+                     float* colsum, void* workspace, size_t ws_bytes, ur_stream_t s);
 /* ur_ce_fwd without a workspace argument and without any allocation.  No counterpart in the reference: it exists for
  * callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  The per-workgroup partial sums live in a device array inside the library (8 KiB per GPU, held

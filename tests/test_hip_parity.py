@@ -1592,6 +1592,78 @@ def test_pooling_inside_the_batchnorm_pass_leaves_the_training_step_bit_identica
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows_shape,classes", [((2, 37, 50), 19), ((1, 64, 128), 19), ((3, 16, 16), 5), ((1, 1, 7), 11)])
+def test_cross_entropy_backward_widened_for_the_head_equals_the_plain_gradient(pkg, rows_shape, classes, dtype):
+    """ur_ce_bwd_padded (gradient rows widened to a multiple of 8 columns with zero fill + per-class sums, the form the 1x1
+    head's kernels read) against ur_ce_bwd: the first `classes` columns bit-identical, the fill zero, the sums equal to the
+    column sums of the stored gradient to fp32 summation order; ignore_index 255 rows, a last span that is not full."""
+    L = pkg._lib
+    import ctypes as C
+    if dtype == torch.float32 and classes > 16:
+        pytest.skip("fp32 rows of more than 16 classes exceed the kernel's 64-byte rows (the caller falls back)")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    n, h, w = rows_shape
+    rows = n * h * w
+    g = torch.Generator().manual_seed(rows + classes)
+    logits = (torch.randn(rows, classes, generator=g) * 3).to(DEV).to(dtype)
+    target = torch.randint(0, classes, (rows,), generator=g)
+    target[torch.rand(rows, generator=g) < 0.2] = 255
+    target = target.to(DEV)
+    code = L.UR_BF16 if dtype == torch.bfloat16 else L.UR_F32
+    cpad = (classes + 7) // 8 * 8
+    assert L.query("ur_ce_bwd_padded_supported", code, classes, cpad)
+    lse, out3 = torch.empty(rows, device=DEV), torch.empty(3, device=DEV)
+    ws = torch.empty(L.query("ur_loss_workspace", rows), dtype=torch.uint8, device=DEV)
+    L.call("ur_ce_fwd", vp(logits), code, vp(target), rows, classes, classes, 255, vp(lse), vp(out3), vp(ws), C.c_size_t(ws.numel()), st)
+    gout = torch.tensor([0.7], device=DEV)
+    plain = torch.empty_like(logits)
+    L.call("ur_ce_bwd", vp(logits), code, vp(target), rows, classes, classes, 255, vp(lse), vp(out3[1:2]), vp(gout), vp(plain), classes, st)
+    wide = torch.full((rows, cpad), 9.0, dtype=dtype, device=DEV)
+    colsum = torch.empty(classes, device=DEV)
+    ws2 = torch.empty(L.query("ur_ce_bwd_padded_workspace", rows), dtype=torch.uint8, device=DEV)
+    L.call("ur_ce_bwd_padded", vp(logits), code, vp(target), rows, classes, 255, vp(lse), vp(out3[1:2]), vp(gout), vp(wide), cpad,
+           vp(colsum), vp(ws2), C.c_size_t(ws2.numel()), st)
+    assert torch.equal(wide[:, :classes], plain)
+    assert bool((wide[:, classes:] == 0).all())
+    ref = plain.double().sum(0)
+    assert torch.allclose(colsum.double(), ref, rtol=1e-5, atol=1e-6 * float(plain.abs().max()) * rows ** 0.5)
+
+
+@pytest.mark.gpu
+def test_loss_gradient_handed_to_the_head_widened_leaves_the_step_unchanged(pkg):
+    """UResNetNewEUCB: one backward pass with the loss writing the head's gradient 24 columns wide and summing it per
+    class against the plain gradient that the head widens and sums itself: every gradient bit-identical except the head's
+    bias gradient (another summation order), and the two passes the head would have run are gone."""
+    M, train, ops = pkg.modules.U_ResNet, pkg.train, pkg.ops
+
+    def run(fused):
+        old, ops.fuse_ce_head_grad = ops.fuse_ce_head_grad, fused
+        try:
+            torch.manual_seed(0)
+            m = M.UResNetNewEUCB(19, 3, 16).set_compute_dtype(torch.bfloat16).to(DEV).train()
+            g = torch.Generator().manual_seed(4)
+            x = torch.randn(2, 3, 128, 256, generator=g).to(DEV)
+            y = torch.randint(0, 19, (2, 128, 256), generator=g)
+            y[torch.rand(y.shape, generator=g) < 0.1] = 255
+            loss = train.compute_loss(m(x), y.to(DEV))
+            loss.backward()
+            torch.cuda.synchronize()
+            return loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()}
+        finally:
+            ops.fuse_ce_head_grad = old
+
+    a, b = run(False), run(True)
+    assert a[0] == b[0]
+    for k in a[1]:
+        if k == "out_conv.2.bias":
+            assert torch.allclose(a[1][k], b[1][k], rtol=1e-4, atol=1e-7), k
+        else:
+            assert torch.equal(a[1][k], b[1][k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,ca,cb,h,w,classes", [(2, 64, 16, 256, 160, 19), (1, 64, 16, 301, 219, 19), (2, 8, 16, 200, 170, 5),
                                                  (1, 32, 24, 263, 251, 8)])
 def test_head_over_the_two_branch_outputs_matches_the_head_over_their_concatenation(pkg, n, ca, cb, h, w, classes):

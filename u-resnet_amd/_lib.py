@@ -125,6 +125,9 @@ SIGNATURES = {
     "ur_ce_fwd_noalloc_prepare": (_i, []),
     "ur_ce_fwd_noalloc": (_i, [_vp, _i, _vp, _ll, _i, _i, _ll, _vp, _vp, _vp]),
     "ur_ce_bwd": (_i, [_vp, _i, _vp, _ll, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ur_ce_bwd_padded_workspace": (_sz, [_ll]),
+    "ur_ce_bwd_padded_supported": (_i, [_i, _i, _i]),
+    "ur_ce_bwd_padded": (_i, [_vp, _i, _vp, _ll, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "ur_bce_fwd": (_i, [_vp, _i, _vp, _ll, _vp, _vp, _sz, _vp]),
     "ur_bce_bwd": (_i, [_vp, _i, _vp, _ll, _vp, _vp, _vp]),
     "ur_argmax_channels": (_i, [_vp, _i, _ll, _i, _i, _vp, _vp]),

@@ -24,6 +24,14 @@ __device__ __forceinline__ void block_sum2(float a, float b, float* out2) {
     }
 }
 
+// exp() of the softmax terms.  bf16 logits: the hardware exponential (v_exp_f32 on x * log2 e, about 1e-6 relative), a
+// tenth of the instructions of the library routine -- the cross-entropy kernels were bound by it (19 calls per pixel), and
+// the result is rounded to bf16 or summed over 19 terms anyway.  fp32 logits keep expf.
+template <typename T> __device__ __forceinline__ float ce_exp(float x) {
+    if constexpr (sizeof(T) == 2) return __expf(x);
+    else return expf(x);
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
                                                     long long rows, int classes, int ld, long long ignore_index,
@@ -34,7 +42,7 @@ __global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* __restrict__ logits
         float m = -INFINITY;
         for (int c = 0; c < classes; ++c) m = fmaxf(m, ur_to_float(row[c]));
         float s = 0.f;
-        for (int c = 0; c < classes; ++c) s += expf(ur_to_float(row[c]) - m);
+        for (int c = 0; c < classes; ++c) s += ce_exp<T>(ur_to_float(row[c]) - m);
         const float l = m + logf(s);
         lse[r] = l;
         const long long t = target[r];
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* __restrict__ logits
         const float l = lse[r];
         for (int c = 0; c < classes; ++c) {
             float g = 0.f;
-            if (valid) g = (expf(ur_to_float(row[c]) - l) - (c == t ? 1.f : 0.f)) * scale;
+            if (valid) g = (ce_exp<T>(ur_to_float(row[c]) - l) - (c == t ? 1.f : 0.f)) * scale;
             drow[c] = ur_from_float<T>(g);
         }
     }
@@ -101,27 +109,56 @@ __global__ __launch_bounds__(NT) void ce_staged_kernel(const T* __restrict__ log
     float scale = 0.f;
     if (BWD) scale = (gout ? gout[0] : 1.f) / count[0];
     const long long nblocks = (rows + NT - 1) / NT;
+    // A full span's pieces are fetched into registers one span ahead (at most 8 per thread: 32 KiB / 16 / 256), so the
+    // memory latency of span b + gridDim.x passes under the arithmetic of span b instead of in front of every span.
+    constexpr int PF = CE_STAGE_BYTES / 16 / NT;
+    uint4 pf[PF];
+#define UR_CE_FETCH(bb)                                                                                    \
+    do {                                                                                                   \
+        const uint4* src_ = reinterpret_cast<const uint4*>(logits + (bb) * NT * classes);                  \
+        _Pragma("unroll") for (int j = 0; j < PF; ++j) {                                                   \
+            const int i_ = (int)threadIdx.x + j * NT;                                                      \
+            if (j * NT < span16) pf[j] = src_[i_ < span16 ? i_ : 0];   /* uniform test; surplus lanes repeat piece 0 */ \
+        }                                                                                                  \
+    } while (0)
+#pragma unroll
+    for (int j = 0; j < PF; ++j) pf[j] = uint4{0u, 0u, 0u, 0u};
+    if ((long long)blockIdx.x < nblocks && ((long long)blockIdx.x + 1) * NT <= rows) UR_CE_FETCH((long long)blockIdx.x);
     for (long long b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const long long r0 = b * NT;
         const int nrows = (int)((rows - r0) < NT ? (rows - r0) : NT);
         const int pieces = nrows == NT ? span16 : (nrows * row_bytes + 15) / 16;
-        const uint4* src = reinterpret_cast<const uint4*>(logits + r0 * classes);
         if (nrows == NT) {
-            for (int i = threadIdx.x; i < pieces; i += NT) stage[i] = src[i];
+#pragma unroll
+            for (int j = 0; j < PF; ++j)
+                if (j * NT < span16 && (int)threadIdx.x + j * NT < span16) stage[threadIdx.x + j * NT] = pf[j];
         } else {                                    // last span: element-wise, it may end inside a 16-byte piece
             for (int i = threadIdx.x; i < nrows * classes; i += NT) tile[i] = logits[r0 * classes + i];
         }
         __syncthreads();
+        if (b + gridDim.x < nblocks && (b + gridDim.x + 1) * NT <= rows) UR_CE_FETCH(b + gridDim.x);
         const int rl = threadIdx.x;
         if (rl < nrows) {
             T* row = tile + rl * classes;
             const long long t = target[r0 + rl];
             const bool valid = t != ignore_index && t >= 0 && t < classes;
             if (!BWD) {
-                float m = -INFINITY;
-                for (int c = 0; c < classes; ++c) m = fmaxf(m, ur_to_float(row[c]));
-                float sum = 0.f;
-                for (int c = 0; c < classes; ++c) sum += expf(ur_to_float(row[c]) - m);
+                float m = -INFINITY, sum = 0.f;
+                if (classes <= 32) {
+                    // the row in registers: 32 unrolled slots with a uniform test each, so the LDS reads are issued back to
+                    // back (a loop with a run-time bound waits for every 2-byte read in turn) and the second pass reads nothing
+                    float v[32];
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) v[c] = c < classes ? ur_to_float(row[c]) : -INFINITY;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) m = fmaxf(m, v[c]);
+#pragma unroll
+                    for (int c = 0; c < 32; ++c)
+                        if (c < classes) sum += ce_exp<T>(v[c] - m);
+                } else {
+                    for (int c = 0; c < classes; ++c) m = fmaxf(m, ur_to_float(row[c]));
+                    for (int c = 0; c < classes; ++c) sum += ce_exp<T>(ur_to_float(row[c]) - m);
+                }
                 const float l = m + logf(sum);
                 lse[r0 + rl] = l;
                 if (valid) { nll += l - ur_to_float(row[t]); cnt += 1.f; }
@@ -129,7 +166,7 @@ __global__ __launch_bounds__(NT) void ce_staged_kernel(const T* __restrict__ log
                 const float l = lse[r0 + rl];
                 for (int c = 0; c < classes; ++c) {
                     float g = 0.f;
-                    if (valid) g = (expf(ur_to_float(row[c]) - l) - (c == t ? 1.f : 0.f)) * scale;
+                    if (valid) g = (ce_exp<T>(ur_to_float(row[c]) - l) - (c == t ? 1.f : 0.f)) * scale;
                     row[c] = ur_from_float<T>(g);
                 }
             }
@@ -146,6 +183,119 @@ __global__ __launch_bounds__(NT) void ce_staged_kernel(const T* __restrict__ log
         __syncthreads();
     }
     if (!BWD) block_sum2(nll, cnt, partial + (size_t)blockIdx.x * 2);
+#undef UR_CE_FETCH
+}
+
+// ce_staged_kernel<T, true> with the gradient rows widened to `dld` columns (zero fill) and the per-class sums of the
+// stored gradient as a by-product: what the 1x1 head behind the loss needs next is exactly this pair -- its streaming
+// kernels take channel counts that are multiples of 8 (19 classes -> 24 columns), and its bias gradient is the column
+// sum.  Rows of at most 64 bytes in and out.  partial[block][32]: per-class sums of the block's rows.
+constexpr int CEP_ROW = 64;                        // bytes per staged row, in and out
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ce_bwd_padded_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                           long long rows, int classes, long long ignore_index,
+                                                           const float* __restrict__ lse, const float* __restrict__ count,
+                                                           const float* __restrict__ gout, T* __restrict__ dlogits, int dld,
+                                                           float* __restrict__ partial) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    __shared__ uint4 stage_in[NT * CEP_ROW / 16];
+    __shared__ u32x4_t stage_out[NT * CEP_ROW / 16];
+    __shared__ float colred[NT / 64][32];
+    T* tin = reinterpret_cast<T*>(stage_in);
+    const int in16 = NT * classes * (int)sizeof(T) / 16;             // exact: 256 * anything
+    const int out_pieces = dld * (int)sizeof(T) / 16;                // 16-byte pieces of a widened row (1 .. 4)
+    const float scale = (gout ? gout[0] : 1.f) / count[0];
+    // per-class sums of the rows this thread handles, in registers (the class loop is unrolled to the kernel's limit of 32
+    // with a uniform test per class, so the arrays are never indexed at run time)
+    float cs[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) cs[c] = 0.f;
+    const long long nblocks = (rows + NT - 1) / NT;
+    for (long long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const long long r0 = b * NT;
+        const int nrows = (int)((rows - r0) < NT ? (rows - r0) : NT);
+        if (nrows == NT) {
+            const uint4* src = reinterpret_cast<const uint4*>(logits + r0 * classes);
+            for (int i = threadIdx.x; i < in16; i += NT) stage_in[i] = src[i];
+        } else {
+            for (int i = threadIdx.x; i < nrows * classes; i += NT) tin[i] = logits[r0 * classes + i];
+        }
+        __syncthreads();
+        const int rl = threadIdx.x;
+        if (rl < nrows) {
+            const T* row = tin + rl * classes;
+            const long long t = target[r0 + rl];
+            const bool valid = t != ignore_index && t >= 0 && t < classes;
+            const float l = lse[r0 + rl];
+            // the widened row is built in registers and goes to LDS as whole 16-byte pieces (rows 48 bytes apart put 16
+            // consecutive lanes on all 64 banks), from where the span leaves as one contiguous run; stores of 16 bytes at a
+            // 48-byte stride straight from the registers were three times slower
+            union { T e[CEP_ROW / (int)sizeof(T)]; u32x4_t q[CEP_ROW / 16]; } o;
+#pragma unroll
+            for (int c = 0; c < CEP_ROW / (int)sizeof(T); ++c) {
+                T gr = ur_from_float<T>(0.f);
+                if (c < classes) {
+                    float g = 0.f;
+                    if (valid) g = (ce_exp<T>(ur_to_float(row[c]) - l) - (c == t ? 1.f : 0.f)) * scale;
+                    gr = ur_from_float<T>(g);
+                    cs[c] += ur_to_float(gr);
+                }
+                o.e[c] = gr;
+            }
+#pragma unroll
+            for (int j = 0; j < CEP_ROW / 16; ++j)
+                if (j < out_pieces) stage_out[rl * out_pieces + j] = o.q[j];
+        }
+        __syncthreads();
+        if (nrows == NT) {
+            u32x4_t* dst = reinterpret_cast<u32x4_t*>(dlogits + r0 * dld);
+            for (int i = threadIdx.x; i < NT * out_pieces; i += NT) __builtin_nontemporal_store(stage_out[i], dst + i);
+        } else {
+            u32x4_t* dst = reinterpret_cast<u32x4_t*>(dlogits + r0 * dld);
+            for (int i = threadIdx.x; i < nrows * out_pieces; i += NT) __builtin_nontemporal_store(stage_out[i], dst + i);
+        }
+    }
+    // block sums: wave butterfly per class, then the four waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        if (c < classes) {
+            const float t = ur_wave_sum(cs[c]);
+            if (lane == 0) colred[wave][c] = t;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+        if ((int)threadIdx.x < classes)
+            for (int wv = 0; wv < NT / 64; ++wv) t += colred[wv][threadIdx.x];
+        partial[(size_t)blockIdx.x * 32 + threadIdx.x] = t;
+    }
+}
+
+// colsum[c] = sum over blocks of partial[block][c], in double, fixed order
+__global__ __launch_bounds__(256) void ce_colsum_finalize_kernel(const float* __restrict__ partial, int nparts, int classes,
+                                                                 float* __restrict__ colsum) {
+    __shared__ double red[8][32];
+    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double t = 0.0;
+    int b = slice;
+    for (; b + 56 < nparts; b += 64) {           // 8 independent loads in flight, added in block order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + 8 * u) * 32 + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += (double)v[u];
+    }
+    for (; b < nparts; b += 8) t += (double)partial[(size_t)b * 32 + col];
+    red[slice][col] = t;
+    __syncthreads();
+    if (threadIdx.x < classes) {
+        double v = 0.0;
+        for (int sl = 0; sl < 8; ++sl) v += red[sl][threadIdx.x];
+        colsum[threadIdx.x] = (float)v;
+    }
 }
 
 template <typename T>
@@ -361,6 +511,32 @@ int ur_ce_bwd(const void* logits, int dtype, const int64_t* target, long long ro
                                                 (const T*)logits, target, rows, classes, ld, ignore_index, lse, count, gout,
                                                 (T*)dlogits, dld));
     return ur_check_launch("ce_bwd");
+}
+
+size_t ur_ce_bwd_padded_workspace(long long rows) { return (size_t)loss_blocks(rows) * 32 * sizeof(float); }
+
+int ur_ce_bwd_padded_supported(int dtype, int classes, int dld) {
+    const int esz = dtype == UR_BF16 ? 2 : (dtype == UR_F32 ? 4 : 0);
+    return esz && classes > 0 && classes <= 32 && dld >= classes && classes * esz <= CEP_ROW && dld * esz <= CEP_ROW &&
+           (dld * esz) % 16 == 0;
+}
+
+int ur_ce_bwd_padded(const void* logits, int dtype, const int64_t* target, long long rows, int classes,
+                     long long ignore_index, const float* lse, const float* count, const float* gout, void* dlogits, int dld,
+                     float* colsum, void* workspace, size_t ws_bytes, ur_stream_t s) {
+    UR_REQUIRE(logits && target && lse && count && dlogits && colsum && workspace && rows > 0, "ce_bwd_padded: bad arguments");
+    UR_REQUIRE(ur_ce_bwd_padded_supported(dtype, classes, dld),
+               "ce_bwd_padded: needs at most 32 classes and rows of at most %d bytes whose padded length is a multiple of 16", CEP_ROW);
+    UR_REQUIRE(((uintptr_t)logits % 16) == 0 && ((uintptr_t)dlogits % 16) == 0, "ce_bwd_padded: tensors must be 16-byte aligned");
+    UR_REQUIRE(ws_bytes >= ur_ce_bwd_padded_workspace(rows), "ce_bwd_padded: workspace too small");
+    const int grid = loss_blocks(rows);
+    UR_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ce_bwd_padded_kernel<T>), dim3(grid), dim3(NT), 0, (hipStream_t)s,
+                                                (const T*)logits, target, rows, classes, ignore_index, lse, count, gout,
+                                                (T*)dlogits, dld, (float*)workspace));
+    if (int e = ur_check_launch("ce_bwd_padded")) return e;
+    hipLaunchKernelGGL(ce_colsum_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)workspace, grid, classes,
+                       colsum);
+    return ur_check_launch("ce_colsum_finalize");
 }
 
 int ur_bce_fwd(const void* logits, int dtype, const float* target, long long count, float* out3, void* workspace,

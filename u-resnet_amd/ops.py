@@ -1066,13 +1066,20 @@ class _BNReluConv1x1(Function):
             dz_ld = _channel_pitch(dz)
             if dz_ld % 8:
                 dz_ld = 0
-        if not dz_ld:
-            dz, dz_ld = _g(dz), cout
         db = dw = None
-        if ctx.bias is not None and ctx.needs_input_grad[11]:
-            db = _colsum(dz.data_ptr(), d.dtype, rows, cout, dz_ld, dev, ctx.bias)
-        if d.cout != cout:
-            dz, dz_ld = _pad_channels(dz, d.cout), d.cout
+        pre = _padded_head_grad(dz, d.cout) if d.cout != cout else None
+        if pre is not None:                  # the loss wrote the gradient widened to d.cout channels and summed it per class
+            dz, dz_ld = pre[0], d.cout
+            if ctx.bias is not None and ctx.needs_input_grad[11]:
+                db = grad_buffer(ctx.bias)
+                db.copy_(pre[1])
+        else:
+            if not dz_ld:
+                dz, dz_ld = _g(dz), cout
+            if ctx.bias is not None and ctx.needs_input_grad[11]:
+                db = _colsum(dz.data_ptr(), d.dtype, rows, cout, dz_ld, dev, ctx.bias)
+            if d.cout != cout:
+                dz, dz_ld = _pad_channels(dz, d.cout), d.cout
         d.out_ld = dz_ld
         # gradient of the activated tensor a = relu(BatchNorm(y)), which exists in no buffer
         da = empty_nhwc(n, c, h, w, y.dtype, dev)
@@ -1183,12 +1190,19 @@ class _BNReluConv1x1Pair(Function):
         c = ca + cb
         rows, dev = n * h * w, ya.device
         cout = weight.shape[0]
-        dz, dz_ld = _g(dz), cout
         db = dw = None
-        if ctx.bias is not None and ctx.needs_input_grad[11]:
-            db = _colsum(dz.data_ptr(), d.dtype, rows, cout, dz_ld, dev, ctx.bias)
-        if d.cout != cout:
-            dz, dz_ld = _pad_channels(dz, d.cout), d.cout
+        pre = _padded_head_grad(dz, d.cout) if d.cout != cout else None
+        if pre is not None:                  # the loss wrote the gradient widened to d.cout channels and summed it per class
+            dz, dz_ld = pre[0], d.cout
+            if ctx.bias is not None and ctx.needs_input_grad[11]:
+                db = grad_buffer(ctx.bias)
+                db.copy_(pre[1])
+        else:
+            dz, dz_ld = _g(dz), cout
+            if ctx.bias is not None and ctx.needs_input_grad[11]:
+                db = _colsum(dz.data_ptr(), d.dtype, rows, cout, dz_ld, dev, ctx.bias)
+            if d.cout != cout:
+                dz, dz_ld = _pad_channels(dz, d.cout), d.cout
         d.out_ld = dz_ld
         # gradients of the two halves of the activated tensor a = relu(BatchNorm(cat)), which exists in no buffer
         da = (empty_nhwc(n, ca, h, w, ya.dtype, dev), empty_nhwc(n, cb, h, w, ya.dtype, dev))
@@ -1601,6 +1615,25 @@ def add(a, b):
 
 
 # ------------------------------------------------------------------------------ losses and masks
+# CE backward -> 1x1 head: the widened gradient and its column sums, keyed by the address of the gradient tensor the loss
+# returned (URESNET_CE_HEAD_GRAD=0: plain gradient, the head widens and sums it itself)
+fuse_ce_head_grad = os.environ.get("URESNET_CE_HEAD_GRAD", "1") != "0"
+_padded_grads = {}
+
+
+def _padded_head_grad(dz, cpad):
+    """(widened gradient [n, cpad, h, w] with zero fill, per-channel sums) when dz is the window the loss's backward returned
+    for exactly this width, untouched since; else None."""
+    hit = _padded_grads.pop(dz.data_ptr(), None) if _padded_grads else None
+    if hit is None:
+        return None
+    buf, colsum, version = hit
+    if (buf.shape[1] != cpad or dz._version != version or tuple(dz.shape[2:]) != tuple(buf.shape[2:]) or dz.shape[0] != buf.shape[0]
+            or _channel_pitch(dz) != cpad or dz.dtype != buf.dtype):
+        return None
+    return buf, colsum
+
+
 class _CrossEntropy(Function):
     @staticmethod
     def forward(ctx, logits, target, ignore_index, count_hook):
@@ -1637,6 +1670,23 @@ class _CrossEntropy(Function):
         logits, target, lse, count = ctx.saved_tensors
         rows, c, ignore_index = ctx.meta
         gout = gout.contiguous().float()
+        cpad = _pad8(c)
+        if (fuse_ce_head_grad and logits.dim() == 4 and cpad != c
+                and query("ur_ce_bwd_padded_supported", _dt(logits), c, cpad)):
+            # The layer behind the loss is the 1x1 head: hand it the gradient in the form its kernels read (rows widened to a
+            # multiple of 8 channels, zero filled) together with the per-class sums (its bias gradient).  The result is a
+            # channel window of the widened tensor; _padded_head_grad() recognises it by address.
+            n, _, h, w = logits.shape
+            buf = empty_nhwc(n, cpad, h, w, logits.dtype, logits.device)
+            colsum = torch.empty(c, dtype=torch.float32, device=logits.device)
+            ws = _workspace(query("ur_ce_bwd_padded_workspace", rows), logits.device)
+            with _Timed("hbm:ce_bwd", logits.numel() * logits.element_size() + buf.numel() * buf.element_size() + rows * 12):
+                call("ur_ce_bwd_padded", logits.data_ptr(), _dt(logits), target.data_ptr(), rows, c, ignore_index, lse.data_ptr(),
+                     count.data_ptr(), gout.data_ptr(), buf.data_ptr(), cpad, colsum.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+            dlogits = alias_window(buf, 0, c)
+            _padded_grads.clear()
+            _padded_grads[dlogits.data_ptr()] = (buf, colsum, dlogits._version)
+            return dlogits, None, None, None
         dlogits = torch.empty_like(logits, memory_format=torch.preserve_format)
         with _Timed("hbm:ce_bwd", 2 * logits.numel() * logits.element_size() + rows * 12):
             call("ur_ce_bwd", logits.data_ptr(), _dt(logits), target.data_ptr(), rows, c, c, ignore_index, lse.data_ptr(),
