@@ -263,6 +263,14 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
 int ur_bn_act_fwd_pool_supported(int dtype, int n, int h, int w, int c);
 int ur_bn_act_fwd_pool(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
                        void* z, int z_ld, void* pooled, uint8_t* idx, int dtype, int n, int h, int w, int c, ur_stream_t s);
+/* ur_bn_act_fwd (dense result, no residual) that also returns ur_bn_stats of its result, for an activation that a second
+ * BatchNorm normalises next (the last stage of the U-Net branch feeding the head's BatchNorm, S/C:283-289 -> S/C:127-133):
+ * partial[ur_bn_act_fwd_stats_rows(rows, c)][c][2] = per-workgroup (sum z, sum z^2) over the rounded values, ready for
+ * ur_bn_finalize[_affine]; z is bit for bit ur_bn_act_fwd's.  bf16, c a multiple of 8 that divides 2048. */
+int ur_bn_act_fwd_stats_supported(int dtype, long long rows, int c);
+size_t ur_bn_act_fwd_stats_rows(long long rows, int c);
+int ur_bn_act_fwd_stats(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                        void* z, int dtype, long long rows, int c, float* partial, ur_stream_t s);
 /* backward pass 1: partial[nparts][c][2] = (sum g, sum g*xhat), g = dz masked by the ReLU (act != 0).
  * The mask comes from the saved output z when z != NULL, else it is recomputed from y (needs gamma, beta;
  * valid only when no residual was added before the activation).  dz_ld = channel pitch of dz in elements

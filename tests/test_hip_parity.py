@@ -1592,6 +1592,83 @@ def test_pooling_inside_the_batchnorm_pass_leaves_the_training_step_bit_identica
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 64, 96), (1, 32, 37, 50), (3, 8, 5, 7), (1, 256, 16, 32), (8, 64, 128, 128)])
+def test_batchnorm_relu_that_also_sums_its_result_matches_the_separate_statistics_pass(pkg, n, c, h, w):
+    """The U-Net branch's last BatchNorm+ReLU (S/C:98-99) feeding the head's BatchNorm (S/C:129) as one pass
+    (ur_bn_act_fwd_stats) against ur_bn_act_fwd + ur_bn_stats: the activated tensor bit-identical; mean and inverse standard
+    deviation after ur_bn_finalize equal to fp32 summation order (the partial rows are grouped differently) and equal to a
+    float64 reduction of the stored tensor to 1e-5."""
+    L = pkg._lib
+    ops = pkg.ops
+    import ctypes as C
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(c + h)
+    rows = n * h * w
+    y = ops.as_activation((torch.randn(n, c, h, w, generator=g) - 0.3).to(DEV), torch.bfloat16)
+    mean, invstd = torch.randn(c, generator=g).to(DEV) * 0.1, torch.rand(c, generator=g).to(DEV) + 0.5
+    gamma, beta = torch.rand(c, generator=g).to(DEV) + 0.5, torch.randn(c, generator=g).to(DEV) * 0.3
+    assert L.query("ur_bn_act_fwd_stats_supported", L.UR_BF16, rows, c)
+    assert not L.query("ur_bn_act_fwd_stats_supported", L.UR_BF16, rows, 24)          # 24 does not divide 2048
+    assert not L.query("ur_bn_act_fwd_stats_supported", L.UR_F32, rows, c)
+
+    def finalize(part):
+        m, s = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        L.call("ur_bn_finalize", vp(part), part.shape[0], rows, c, 1e-5, 0.1, vp(m), vp(s), None, None, None, st)
+        return m, s
+
+    za = torch.empty(n, h, w, c, dtype=torch.bfloat16, device=DEV)
+    L.call("ur_bn_act_fwd", vp(y), vp(mean), vp(invstd), vp(gamma), vp(beta), None, 1, vp(za), L.UR_BF16, rows, c, c, st)
+    pa = torch.empty(L.query("ur_bn_stats_rows", rows, c), c, 2, device=DEV)
+    L.call("ur_bn_stats", vp(za), L.UR_BF16, rows, c, vp(pa), st)
+    zb = torch.empty_like(za)
+    pb = torch.full((L.query("ur_bn_act_fwd_stats_rows", rows, c), c, 2), float("nan"), device=DEV)
+    L.call("ur_bn_act_fwd_stats", vp(y), vp(mean), vp(invstd), vp(gamma), vp(beta), 1, vp(zb), L.UR_BF16, rows, c, vp(pb), st)
+    assert torch.equal(za, zb)
+    z64 = za.double().reshape(rows, c)
+    ref_m, ref_s = z64.mean(0), (z64.var(0, unbiased=False) + 1e-5).rsqrt()
+    (ma, sa), (mb, sb) = finalize(pa), finalize(pb)
+    for got_m, got_s in ((ma, sa), (mb, sb)):
+        assert torch.allclose(got_m.double(), ref_m, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(got_s.double(), ref_s, rtol=1e-5, atol=0)
+    assert torch.allclose(ma, mb, rtol=2e-6, atol=1e-7) and torch.allclose(sa, sb, rtol=2e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_head_statistics_taken_from_the_branch_s_last_pass_leave_the_training_step_unchanged(pkg):
+    """UResNetNewEUCB: one optimiser step with the head's BatchNorm sums of the U-Net branch's result produced by that
+    branch's last BatchNorm+ReLU pass, against the separate ur_bn_stats pass over it: the statistics differ only in fp32
+    summation order, so loss and logits agree to bf16 resolution and the updated parameters to Adam's step size; the fused
+    pass really runs (one launch) and the read-back pass is gone."""
+    M, train, ops = pkg.modules.U_ResNet, pkg.train, pkg.ops
+
+    def run(fused):
+        old, ops.fuse_bn_out_stats = ops.fuse_bn_out_stats, fused
+        try:
+            torch.manual_seed(0)
+            m = M.UResNetNewEUCB(19, 3, 64).set_compute_dtype(torch.bfloat16).to(DEV).train()
+            opt = train.Adam(m.parameters(), lr=1e-3)
+            g = torch.Generator().manual_seed(9)
+            x = torch.randn(2, 3, 128, 256, generator=g).to(DEV)
+            y = torch.randint(0, 19, (2, 128, 256), generator=g).to(DEV)
+            ops.kernel_timings, ops.kernel_timing_tags = [], {"hbm:bn_fwd_stats"}
+            loss, out = train.seg_train_step(m, opt, x, y)
+            tags = [t[0] for t in ops.kernel_timings]
+            torch.cuda.synchronize()
+            return loss.item(), out.float(), [p.detach().clone() for p in m.parameters()], tags, m.out_conv[0].running_mean.clone()
+        finally:
+            ops.fuse_bn_out_stats, ops.kernel_timings, ops.kernel_timing_tags = old, None, None
+
+    a, b = run(False), run(True)
+    assert a[3].count("hbm:bn_fwd_stats") == 0 and b[3].count("hbm:bn_fwd_stats") == 1
+    assert abs(a[0] - b[0]) <= 2e-3 * abs(a[0])
+    assert torch.allclose(a[1], b[1], rtol=2e-2, atol=2e-2)
+    assert torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-7)
+    for p, q in zip(a[2], b[2]):
+        assert (p - q).abs().max().item() <= 2.1e-3          # (Adam moves every weight by at most lr in the first step)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("rows_shape,classes", [((2, 37, 50), 19), ((1, 64, 128), 19), ((3, 16, 16), 5), ((1, 1, 7), 11)])
 def test_cross_entropy_backward_widened_for_the_head_equals_the_plain_gradient(pkg, rows_shape, classes, dtype):

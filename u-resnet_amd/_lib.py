@@ -99,6 +99,9 @@ SIGNATURES = {
     "ur_bn_bwd_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ur_bn_act_fwd_pool_supported": (_i, [_i, _i, _i, _i, _i]),
     "ur_bn_act_fwd_pool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ur_bn_act_fwd_stats_supported": (_i, [_i, _ll, _i]),
+    "ur_bn_act_fwd_stats_rows": (_sz, [_ll, _i]),
+    "ur_bn_act_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _vp, _vp]),
     "ur_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _ll, _i, _i, _vp]),
     "ur_maxpool2x2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ur_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -388,6 +388,54 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_bf16x8_kernel(const bf16_t* __r
     }
 }
 
+// bn_act_fwd_bf16x8_kernel (dense result, no residual) that also sums its result per channel (sum z, sum z^2 of the
+// ROUNDED values, i.e. what bn_stats_kernel would read back) for a BatchNorm that follows: one pass over z less.
+// Needs NT * 8 % C == 0: a thread then stays on one channel group (tid % (C / 8)) for its whole walk.  The partial row of
+// a workgroup has bn_stats_kernel's layout, partial[blockIdx.x][C][2], and sums the row slots in a fixed order.
+__global__ __launch_bounds__(NT) void bn_act_fwd_stats_bf16x8_kernel(const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, int act, bf16_t* __restrict__ z,
+                                                                     long long total, int C, float* __restrict__ partial) {
+    __shared__ float red[NT * 16];
+    const long long stride = (long long)gridDim.x * NT * 8;
+    long long i = (blockIdx.x * (long long)NT + threadIdx.x) * 8;
+    const int tid = threadIdx.x, cq = C >> 3, slots = NT / cq;
+    Chan8 k;
+    k.load(mean, invstd, gamma, beta, (tid % cq) * 8);
+    float s0[8], s1[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    auto one = [&](const bf16x8_t& y8, long long zi) {
+        bf16x8_t o8;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            float o = ((float)y8[v] - k.m[v]) * k.is[v] * k.ga[v] + k.be[v];      // bn_act_fwd_bf16x8_kernel's expression
+            if (act) o = fmaxf(o, 0.f);
+            o8[v] = (bf16_t)o;
+            const float r = (float)o8[v];
+            s0[v] += r; s1[v] += r * r;
+        }
+        st_stream(z + zi, o8);
+    };
+    for (; i + (EW_UNROLL - 1) * stride < total; i += EW_UNROLL * stride) {
+        bf16x8_t y8[EW_UNROLL];
+#pragma unroll
+        for (int u = 0; u < EW_UNROLL; ++u) y8[u] = ld_stream(y + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < EW_UNROLL; ++u) one(y8[u], i + u * stride);
+    }
+    for (; i < total; i += stride) one(ld_stream(y + i), i);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { red[(v * 2) * NT + tid] = s0[v]; red[(v * 2 + 1) * NT + tid] = s1[v]; }
+    __syncthreads();
+    for (int o = tid; o < cq * 16; o += NT) {
+        const int q = o / cq, g = o - q * cq;
+        float t = 0.f;
+        for (int sl = 0; sl < slots; ++sl) t += red[q * NT + sl * cq + g];
+        partial[((size_t)blockIdx.x * C + g * 8 + (q >> 1)) * 2 + (q & 1)] = t;
+    }
+}
+
 // bn_act_fwd_bf16x8_kernel and MaxPool2d(2, 2) of its result in one pass: a thread owns 8 channels of one 2x2 window --
 // four 16-byte loads of y, four stores of z (possibly into a channel window), one store of the maximum and of the
 // 8 position bytes.  z is bit for bit what the plain kernel writes (same expression) and the maximum is taken over the
@@ -860,6 +908,26 @@ int ur_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
                                 (const T*)y, mean, invstd, gamma, beta, (const T*)residual, act, (T*)z, total, c, z_ld);
     });
     return ur_check_launch("bn_act_fwd");
+}
+
+int ur_bn_act_fwd_stats_supported(int dtype, long long rows, int c) {
+    return dtype == UR_BF16 && rows > 0 && c >= 8 && c % 8 == 0 && (NT * 8) % c == 0;
+}
+
+size_t ur_bn_act_fwd_stats_rows(long long rows, int c) { return (size_t)ew_grid(rows * c / 8, c); }
+
+int ur_bn_act_fwd_stats(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                        void* z, int dtype, long long rows, int c, float* partial, ur_stream_t s) {
+    UR_REQUIRE(y && mean && invstd && gamma && beta && z && partial, "bn_act_fwd_stats: null pointer");
+    UR_REQUIRE(ur_bn_act_fwd_stats_supported(dtype, rows, c),
+               "bn_act_fwd_stats: needs bf16 and a channel count that divides %d (multiple of 8)", NT * 8);
+    UR_REQUIRE(aligned16(y) && aligned16(z) && aligned16(mean) && aligned16(invstd) && aligned16(gamma) && aligned16(beta),
+               "bn_act_fwd_stats: pointers must be 16-byte aligned");
+    const long long total = rows * c;
+    const int grid = ew_grid(total / 8, c);
+    hipLaunchKernelGGL(bn_act_fwd_stats_bf16x8_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)y, mean, invstd,
+                       gamma, beta, act, (bf16_t*)z, total, c, partial);
+    return ur_check_launch("bn_act_fwd_stats");
 }
 
 int ur_bn_act_fwd_pool_supported(int dtype, int n, int h, int w, int c) {

@@ -59,7 +59,7 @@ class _TwoBranch(ResTrunk):
             # tensor are 128- and 32-byte runs at a 160-byte pitch: partial memory lines in every pass that touches them.)
             with on_side():
                 res_out = self.Upsample(res)
-            u_out = unet_branch_forward(self, x)
+            u_out = unet_branch_forward(self, x, out_stats=self.out_conv[0].training)   # (the head's BatchNorm comes next)
             if fork is not None:
                 fork.join(res_out)
             z = ops.bn_relu_conv1x1_pair(ops.dense(u_out), ops.dense(res_out), self.out_conv[0], head_conv)

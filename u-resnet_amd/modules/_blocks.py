@@ -38,13 +38,13 @@ def act_layer(act, inplace=False, neg_slope=0.2, n_prelu=1):
     raise NotImplementedError('activation layer [%s] is not found' % act)
 
 
-def _cba(seq, x, i, out=None, pool=False):
+def _cba(seq, x, i, out=None, pool=False, out_stats=False):
     """Run seq[i] (conv), seq[i+1] (BN), seq[i+2] (activation) fused when the activation is ReLU.  `out`: optional
     channel window for the result (honoured on the fused path only; callers compare data_ptr()).  pool: the caller
-    max-pools the result next (ops.bn_act)."""
+    max-pools the result next, out_stats: the caller normalises it with another BatchNorm next (ops.bn_act)."""
     conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
     if type(act) in _ACT_CODES:
-        return conv_bn_act(x, conv, bn, _ACT_CODES[type(act)], out=out, pool=pool)
+        return conv_bn_act(x, conv, bn, _ACT_CODES[type(act)], out=out, pool=pool, out_stats=out_stats)
     return act(conv_bn_act(x, conv, bn, _lib.ACT_NONE))
 
 
@@ -167,12 +167,13 @@ class DoubleConv(hnn.Sequential):
             hnn.BatchNorm2d(out_channels),
             hnn.ReLU(inplace=True))
 
-    def forward(self, x, out=None, pool=False):
-        """out: optional channel window for the result; pool: the caller max-pools the result next (see _cba)."""
+    def forward(self, x, out=None, pool=False, out_stats=False):
+        """out: optional channel window for the result; pool: the caller max-pools the result next, out_stats: the caller
+        normalises it with another BatchNorm next (see _cba)."""
         x = ops.as_activation(x, act_dtype(x))
         if has_hooks(*self):
             return super().forward(x)
-        return _cba(self, _cba(self, x, 0), 3, out, pool)
+        return _cba(self, _cba(self, x, 0), 3, out, pool, out_stats)
 
 
 class Down(hnn.Sequential):
@@ -190,18 +191,20 @@ class Up(hnn.Module):
         self.up = hnn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
         self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2, cat=None, out=None):
+    def forward(self, x1, x2, cat=None, out=None, out_stats=False):
         """cat: the pre-allocated concatenated tensor whose first channel window already holds x2 (x2 is then
-        an alias of that window, see unet_branch_forward).  out: optional channel window for the result."""
+        an alias of that window, see unet_branch_forward).  out: optional channel window for the result.
+        out_stats: the caller normalises the result with another BatchNorm next (see _cba)."""
         if not has_hooks(self.up) and x2.shape[2] == 2 * x1.shape[2] and x2.shape[3] == 2 * x1.shape[3]:
             # the transposed convolution writes straight into its half of the concatenated tensor
             x1 = ops.as_activation(x1, act_dtype(x1))
             if cat is None:
                 x2 = ops.as_activation(x2, x1.dtype)
-            return self.conv(ops.conv_transpose2x2_cat(x1, self.up.weight, self.up.bias, self.up._packs, x2, cat), out=out)
+            return self.conv(ops.conv_transpose2x2_cat(x1, self.up.weight, self.up.bias, self.up._packs, x2, cat), out=out,
+                             out_stats=out_stats)
         x1 = self.up(x1)
         x2 = ops.as_activation(x2, x1.dtype)
-        return self.conv(ops.cat_pad(x2, x1), out=out)
+        return self.conv(ops.cat_pad(x2, x1), out=out, out_stats=out_stats)
 
 
 class OutConv(hnn.Sequential):
@@ -389,8 +392,9 @@ def _pool_and_skip(down, x):
     return None, x
 
 
-def unet_branch_forward(m, x, out=None):
-    """out: optional channel window for the branch's result (see Up.forward)."""
+def unet_branch_forward(m, x, out=None, out_stats=False):
+    """out: optional channel window for the branch's result; out_stats: the caller normalises the result with another
+    BatchNorm next (see Up.forward)."""
     x1, c1 = _skip_into_cat(m.in_conv, x, m.up4, pool_next=_pools_with_skip(m.down1))
     p1, x1 = _pool_and_skip(m.down1, x1)
     x2, c2 = _skip_into_cat(m.down1, x1, m.up3, p1, pool_next=_pools_with_skip(m.down2))
@@ -403,4 +407,4 @@ def unet_branch_forward(m, x, out=None):
     u = m.up1(x5, x4, c4)
     u = m.up2(u, x3, c3)
     u = m.up3(u, x2, c2)
-    return m.up4(u, x1, c1, out=out)
+    return m.up4(u, x1, c1, out=out, out_stats=out_stats)

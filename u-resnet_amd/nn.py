@@ -189,7 +189,7 @@ def has_hooks(*mods):
 fuse_eval_bn = True          # False: inference runs convolution and BatchNorm as separate kernels (A/B comparisons)
 
 
-def conv_bn_act(x, conv, bn, act=_lib.ACT_RELU, residual=None, out=None, pool=False):
+def conv_bn_act(x, conv, bn, act=_lib.ACT_RELU, residual=None, out=None, pool=False, out_stats=False):
     """conv -> BatchNorm (training statistics taken from the conv kernel's epilogue) -> (+residual) -> act.
     Inference (bn in eval mode under torch.no_grad()): BatchNorm is folded into the convolution's epilogue."""
     if (fuse_eval_bn and not bn.training and not torch.is_grad_enabled() and isinstance(conv, Conv2d) and conv.groups == 1
@@ -199,4 +199,4 @@ def conv_bn_act(x, conv, bn, act=_lib.ACT_RELU, residual=None, out=None, pool=Fa
         if z is not None:
             return z
     y, stats = conv.raw(x, want_stats=bn.training)
-    return ops.bn_act(y, bn, residual=residual, stats=stats, act=act, out=out, pool=pool)
+    return ops.bn_act(y, bn, residual=residual, stats=stats, act=act, out=out, pool=pool, out_stats=out_stats)

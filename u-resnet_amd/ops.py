@@ -874,7 +874,7 @@ class _BNRecord:
 class _BNAct(Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, residual, stats, running_mean, running_var, nbt, training, momentum, eps, act, out, rec,
-                pool=None):
+                pool=None, ostats=None):
         _require_gpu(y)
         n, c, h, w = y.shape
         rows = n * h * w
@@ -911,6 +911,14 @@ class _BNAct(Function):
                 call("ur_bn_act_fwd_pool", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
                      z.data_ptr(), z_ld, pooled.data_ptr(), idx.data_ptr(), _dt(y), n, h, w, c, _stream())
             pool.append((pooled, idx))
+        elif (ostats is not None and residual is None and z_ld == c and z.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
+                and y.is_contiguous(memory_format=CL) and query("ur_bn_act_fwd_stats_supported", _dt(y), rows, c)):
+            # a second BatchNorm normalises the result next (bn_relu_conv1x1_pair): its sums come out of this pass
+            part = torch.empty((query("ur_bn_act_fwd_stats_rows", rows, c), c, 2), dtype=torch.float32, device=dev)
+            with _Timed("hbm:bn_fwd_stats", tb * 2):
+                call("ur_bn_act_fwd_stats", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
+                     z.data_ptr(), _dt(y), rows, c, part.data_ptr(), _stream())
+            ostats.append(part)
         else:
             with _Timed("hbm:bn_fwd", tb * (3 if residual is not None else 2)):
                 call("ur_bn_act_fwd", y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -969,33 +977,40 @@ class _BNAct(Function):
             call("ur_bn_act_bwd_apply", dz.data_ptr(), y.data_ptr(), _p(z), mean.data_ptr(), invstd.data_ptr(),
                  gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ctx.act, int(ctx.eval), dy.data_ptr(), _p(dres),
                  _dt(y), rows, c, dz_ld, _stream())
-        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 fuse_bn_pool = os.environ.get("URESNET_BN_POOL", "1") != "0"    # False: the max-pool after an encoder stage reads the stage's result back
+fuse_bn_out_stats = os.environ.get("URESNET_BN_OUT_STATS", "1") != "0"   # False: a BatchNorm over a BatchNorm+ReLU result reads it back for its sums
 
 
-def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU, out=None, pool=False):
+def bn_act(y, bn, residual=None, stats=None, act=_lib.ACT_RELU, out=None, pool=False, out_stats=False):
     """BatchNorm2d module `bn` applied to y, fused with an optional residual add and ReLU.  `out`: optional
     channel window (alias_window) to write the result into.  pool: the caller hands the result to maxpool2x2_skip next;
     where the fused kernel covers the shape the pooled tensor is computed in the same pass and travels with the result
-    (attribute `_ur_pooled`)."""
+    (attribute `_ur_pooled`).  out_stats: the caller normalises the result with another BatchNorm next
+    (bn_relu_conv1x1_pair); where the fused kernel covers the shape the per-channel sums of the result travel with it
+    (attribute `_ur_out_stats`)."""
     training = bn.training or bn.running_mean is None
     if training and bn.momentum is None:
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not implemented")
     track = training and bn.track_running_stats and bn.running_mean is not None
     rec = _BNRecord() if (fuse_bn_bwd_sums and training and torch.is_grad_enabled()) else None
     hold = [] if (pool and fuse_bn_pool and residual is None and y.is_cuda and y.dim() == 4 and torch.is_grad_enabled()) else None
+    ohold = [] if (out_stats and fuse_bn_out_stats and hold is None and residual is None and out is None and y.is_cuda
+                   and y.dim() == 4) else None
     z = _BNAct.apply(y, bn.weight, bn.bias, residual, stats if training else None,
                      bn.running_mean if (track or not training) else None,
                      bn.running_var if (track or not training) else None,
                      bn.num_batches_tracked if track else None,
                      training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, act,
-                     None if out is None else (out,), rec, hold)
+                     None if out is None else (out,), rec, hold, ohold)
     if rec is not None and getattr(rec, "y", None) is not None:
         z._ur_bn = rec           # a following 3x3 convolution picks it up (see _BNRecord)
     if hold:
         z._ur_pooled = hold[0] + (z.data_ptr(), z._version)
+    if ohold:
+        z._ur_out_stats = (ohold[0], z.data_ptr(), z._version)
     return z
 
 
@@ -1147,7 +1162,7 @@ class _BNReluConv1x1Pair(Function):
     two dense tensors stream at full rate."""
 
     @staticmethod
-    def forward(ctx, ya, yb, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, weight, bias):
+    def forward(ctx, ya, yb, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, weight, bias, stats_a=None):
         _require_gpu(ya)
         n, ca, h, w = ya.shape
         cb = yb.shape[1]
@@ -1161,8 +1176,10 @@ class _BNReluConv1x1Pair(Function):
         off = lambda t, o: None if t is None else t.data_ptr() + 4 * o      # noqa: E731  (fp32 vectors: element o)
         if training:
             for y, o, ci, aff in parts:
-                stats = torch.empty((query("ur_bn_stats_rows", rows, ci), ci, 2), dtype=torch.float32, device=dev)
-                call("ur_bn_stats", y.data_ptr(), _dt(y), rows, ci, stats.data_ptr(), _stream())
+                stats = stats_a if o == 0 else None          # (the producer of ya summed its result: bn_act(out_stats=True))
+                if stats is None:
+                    stats = torch.empty((query("ur_bn_stats_rows", rows, ci), ci, 2), dtype=torch.float32, device=dev)
+                    call("ur_bn_stats", y.data_ptr(), _dt(y), rows, ci, stats.data_ptr(), _stream())
                 call("ur_bn_finalize_affine", stats.data_ptr(), stats.shape[0], rows, ci, eps, momentum, off(mean, o), off(invstd, o),
                      off(running_mean, o), off(running_var, o), _p(nbt) if o == 0 else None, off(gamma, o), off(beta, o),
                      aff.data_ptr(), _stream())
@@ -1235,7 +1252,7 @@ class _BNReluConv1x1Pair(Function):
                      off(beta, o), sums.data_ptr(), _lib.ACT_RELU, int(ctx.eval), dy.data_ptr(), None, _dt(y), rows, ci, ci,
                      _stream())
             dys.append(dy)
-        return dys[0], dys[1], dgamma, dbeta, None, None, None, None, None, None, dw, db
+        return dys[0], dys[1], dgamma, dbeta, None, None, None, None, None, None, dw, db, None
 
 
 fuse_merge_into_head = os.environ.get("URESNET_MERGE_PAIR", "1") != "0"    # False: the Feature Merge builds the merged tensor
@@ -1271,11 +1288,17 @@ def bn_relu_conv1x1_pair(ya, yb, bn, conv):
         return None
     training = bn.training or bn.running_mean is None
     track = training and bn.track_running_stats and bn.running_mean is not None
+    pre = getattr(ya, "_ur_out_stats", None)
+    stats_a = None
+    if pre is not None:
+        ya._ur_out_stats = None
+        if training and pre[1] == ya.data_ptr() and pre[2] == ya._version and tuple(pre[0].shape[1:]) == (ya.shape[1], 2):
+            stats_a = pre[0]                             # (sum, sum of squares) of ya from the pass that wrote it, unmodified since
     return _BNReluConv1x1Pair.apply(ya, yb, bn.weight, bn.bias,
                                     bn.running_mean if (track or not training) else None,
                                     bn.running_var if (track or not training) else None,
                                     bn.num_batches_tracked if track else None,
-                                    training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, conv.weight, conv.bias)
+                                    training, 0.0 if bn.momentum is None else bn.momentum, bn.eps, conv.weight, conv.bias, stats_a)
 
 
 # ------------------------------------------------------------------------------ spatial ops
