@@ -1635,6 +1635,72 @@ def test_batchnorm_relu_that_also_sums_its_result_matches_the_separate_statistic
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nparts,c", [(65, 64), (200, 19), (2048, 64), (4096, 8), (1000, 100), (129, 1024), (64, 64)])
+def test_one_launch_reduction_over_many_partial_rows_matches_a_float64_sum(pkg, nparts, c, monkeypatch):
+    """ur_bn_finalize / ur_bn_finalize_affine / ur_bn_bwd_finalize over more than 64 partial rows run as one launch
+    (row slots in parallel, summed in double in a fixed order) instead of a folding launch plus a one-thread-per-channel
+    launch: mean, inverse standard deviation, folded constants, running statistics (torch.nn.BatchNorm2d's update, unbiased
+    variance), the batch counter and the backward sums against a float64 reduction of the same rows (1e-6), against the
+    two-launch path (URESNET_REDUCE_ROWS=0; fp32 rounding of its folded rows apart), and run to run bit-identical.
+    Channel counts that are not multiples of 8 and row counts that are not multiples of the 128 row slots included."""
+    L = pkg._lib
+    import ctypes as C
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(nparts + c)
+    count = nparts * 512
+    x1 = torch.randn(nparts, c, generator=g) * 30 + 100
+    x2 = x1.abs() * 2 + torch.rand(nparts, c, generator=g) * 4000
+    part0 = torch.stack([x1, x2], dim=2).contiguous().to(DEV)
+    gamma, beta = torch.rand(c, generator=g).to(DEV) + 0.5, torch.randn(c, generator=g).to(DEV)
+    s64 = part0.double().sum(0)
+    m64 = s64[:, 0] / count
+    v64 = (s64[:, 1] / count - m64 * m64).clamp_min(0)
+
+    def forward(affine):
+        part = part0.clone()
+        mean, invstd, aff = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(2 * c, device=DEV)
+        rm, rv = torch.full((c,), 0.25, device=DEV), torch.full((c,), 2.0, device=DEV)
+        nbt = torch.tensor(7, dtype=torch.int64, device=DEV)
+        if affine:
+            L.call("ur_bn_finalize_affine", vp(part), nparts, count, c, 1e-5, 0.1, vp(mean), vp(invstd), vp(rm), vp(rv), vp(nbt),
+                   vp(gamma), vp(beta), vp(aff), st)
+        else:
+            L.call("ur_bn_finalize", vp(part), nparts, count, c, 1e-5, 0.1, vp(mean), vp(invstd), vp(rm), vp(rv), vp(nbt), st)
+        torch.cuda.synchronize()
+        return mean, invstd, rm, rv, aff if affine else None, int(nbt.item())
+
+    def backward():
+        part = part0.clone()
+        sums, dg, db = torch.empty(c, 2, device=DEV), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        L.call("ur_bn_bwd_finalize", vp(part), nparts, c, vp(sums), vp(dg), vp(db), st)
+        torch.cuda.synchronize()
+        return sums, dg, db
+
+    monkeypatch.setenv("URESNET_REDUCE_ROWS", "1")
+    new_f, new_a, new_b = forward(False), forward(True), backward()
+    again = forward(True)
+    monkeypatch.setenv("URESNET_REDUCE_ROWS", "0")
+    old_a, old_b = forward(True), backward()
+    for got in (new_f, new_a):
+        assert torch.allclose(got[0].double(), m64, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(got[1].double(), (v64 + 1e-5).rsqrt(), rtol=1e-6, atol=0)
+        assert torch.allclose(got[2].double(), 0.9 * 0.25 + 0.1 * m64, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(got[3].double(), 0.9 * 2.0 + 0.1 * v64 * count / (count - 1), rtol=1e-6, atol=1e-6)
+        assert got[5] == 8
+    k = gamma * new_a[1]
+    assert torch.equal(new_a[4][:c], k) and torch.allclose(new_a[4][c:], beta - new_a[0] * k, rtol=1e-6, atol=1e-6)   # (fused multiply-add)
+    for a, b in zip(new_a[:5], again[:5]):
+        assert torch.equal(a, b)
+    for a, b in zip(new_a[:5], old_a[:5]):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-6)
+    assert torch.allclose(new_b[0].double(), s64, rtol=1e-6, atol=1e-3)
+    assert torch.equal(new_b[0][:, 1], new_b[1]) and torch.equal(new_b[0][:, 0], new_b[2])       # (dgamma, dbeta) = (sum g*xhat, sum g)
+    for a, b in zip(new_b, old_b):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-3)
+
+
+@pytest.mark.gpu
 def test_head_statistics_taken_from_the_branch_s_last_pass_leave_the_training_step_unchanged(pkg):
     """UResNetNewEUCB: one optimiser step with the head's BatchNorm sums of the U-Net branch's result produced by that
     branch's last BatchNorm+ReLU pass, against the separate ur_bn_stats pass over it: the statistics differ only in fp32

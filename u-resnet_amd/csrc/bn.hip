@@ -4,6 +4,7 @@
 // reductions done as thread-private sums -> LDS tree over the row slots of a workgroup ->
 // one partial row per workgroup (summed later in a fixed order: reproducible, no atomics).
 #include "ur_common.h"
+#include <stdlib.h>
 
 #ifndef UR_RED_GRID_CAP
 #define UR_RED_GRID_CAP 2048
@@ -217,6 +218,83 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts
         double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
     }
+}
+
+// The sums over MANY partial rows [nparts][C][2] and the epilogue of bn_finalize_kernel (FINALIZE) or sum_partials_kernel
+// (!FINALIZE) in one launch: a 1024-thread workgroup owns 8 channels (64 contiguous bytes per row), thread (slot, channel)
+// walks rows slot, slot + 128, ... with 8 loads in flight and sums in double; the 128 slot sums are added in a fixed order
+// through LDS (16 at a time, then 8).  Replaces fold_partials_kernel + the one-thread-per-channel kernel where the row
+// count is large: one launch and no intermediate rounding to float.
+template <bool FINALIZE>
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ partial, int nparts, long long count, int C,
+                                                           float eps, float momentum, float* __restrict__ o0, float* __restrict__ o1,
+                                                           float* __restrict__ rmean, float* __restrict__ rvar,
+                                                           long long* __restrict__ nbt, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ aff,
+                                                           float* __restrict__ sums) {
+    __shared__ double red[128][16];
+    __shared__ double red2[8][16];
+    const int t = threadIdx.x, ch = t & 7, slot = t >> 3;
+    const int c = blockIdx.x * 8 + ch;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+        const float2* src = reinterpret_cast<const float2*>(partial) + c;
+        int p = slot;
+        for (; p + 7 * 128 < nparts; p += 8 * 128) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(p + u * 128) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a0 += v[u].x; a1 += v[u].y; }
+        }
+        for (; p < nparts; p += 128) { const float2 v = src[(size_t)p * C]; a0 += v.x; a1 += v.y; }
+    }
+    red[slot][ch * 2] = a0;
+    red[slot][ch * 2 + 1] = a1;
+    __syncthreads();
+    if (t < 128) {
+        const int o = t & 15, j = t >> 4;
+        double q = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) q += red[j * 16 + k][o];
+        red2[j][o] = q;
+    }
+    __syncthreads();
+    if (FINALIZE && blockIdx.x == 0 && t == 0 && nbt) *nbt += 1;
+    if (t >= 8 || c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1 += red2[j][ch * 2]; s2 += red2[j][ch * 2 + 1]; }
+    if (!FINALIZE) {
+        if (sums) { sums[(size_t)c * 2] = (float)s1; sums[(size_t)c * 2 + 1] = (float)s2; }
+        if (o0) o0[c] = (float)s1;
+        if (o1) o1[c] = (float)s2;
+        return;
+    }
+    const double m = s1 / (double)count;                     // from here on: bn_finalize_kernel's epilogue
+    double var = s2 / (double)count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+    o0[c] = mf;
+    o1[c] = isf;
+    if (aff) {
+        const float k = gamma[c] * isf;
+        aff[c] = k;
+        aff[C + c] = beta[c] - mf * k;
+    }
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
+    if (rvar) {
+        const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+#ifndef UR_REDUCE_ROWS_MIN
+#define UR_REDUCE_ROWS_MIN (FOLD_CHUNKS * 2 + 1)     // the row counts that used to be folded first
+#endif
+bool reduce_rows_enabled() {
+    const char* e = getenv("URESNET_REDUCE_ROWS");
+    return !(e && e[0] == '0');
 }
 
 __global__ void bn_eval_affine_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
@@ -847,6 +925,12 @@ int ur_bn_finalize(float* partial, int nparts, long long count, int c, float eps
                    float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
                    ur_stream_t s) {
     UR_REQUIRE(partial && mean && invstd && nparts > 0 && count > 0 && c > 0, "bn_finalize: bad arguments");
+    if (nparts >= UR_REDUCE_ROWS_MIN && reduce_rows_enabled()) {
+        hipLaunchKernelGGL(reduce_rows_kernel<true>, dim3(ur_cdiv(c, 8)), dim3(1024), 0, (hipStream_t)s, partial, nparts, count, c,
+                           eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+        return ur_check_launch("bn_finalize");
+    }
     nparts = fold_partials<2>(partial, nparts, c, (hipStream_t)s);
     if (int e = ur_check_launch("bn_fold_partials")) return e;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, count, c,
@@ -859,6 +943,12 @@ int ur_bn_finalize_affine(float* partial, int nparts, long long count, int c, fl
                           float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
                           const float* gamma, const float* beta, float* aff, ur_stream_t s) {
     UR_REQUIRE(partial && mean && invstd && gamma && beta && aff && nparts > 0 && count > 0 && c > 0, "bn_finalize_affine: bad arguments");
+    if (nparts >= UR_REDUCE_ROWS_MIN && reduce_rows_enabled()) {
+        hipLaunchKernelGGL(reduce_rows_kernel<true>, dim3(ur_cdiv(c, 8)), dim3(1024), 0, (hipStream_t)s, partial, nparts, count, c,
+                           eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta, aff,
+                           (float*)nullptr);
+        return ur_check_launch("bn_finalize_affine");
+    }
     nparts = fold_partials<2>(partial, nparts, c, (hipStream_t)s);
     if (int e = ur_check_launch("bn_fold_partials")) return e;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, count, c,
@@ -1023,6 +1113,12 @@ int ur_maxpool2x2_bwd_bnsums(const void* dpool, const uint8_t* idx, void* dz, co
 int ur_bn_bwd_finalize(float* partial, int nparts, int c, float* sums, float* dgamma, float* dbeta,
                        ur_stream_t s) {
     UR_REQUIRE(partial && sums && nparts > 0 && c > 0, "bn_bwd_finalize: bad arguments");
+    if (nparts >= UR_REDUCE_ROWS_MIN && reduce_rows_enabled()) {
+        hipLaunchKernelGGL(reduce_rows_kernel<false>, dim3(ur_cdiv(c, 8)), dim3(1024), 0, (hipStream_t)s, partial, nparts, 0LL, c,
+                           0.f, 0.f, dbeta, dgamma, (float*)nullptr, (float*)nullptr, (long long*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, sums);
+        return ur_check_launch("bn_bwd_finalize");
+    }
     nparts = fold_partials<2>(partial, nparts, c, (hipStream_t)s);
     if (int e = ur_check_launch("bn_fold_partials")) return e;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(ur_cdiv(c, 64)), dim3(64), 0, (hipStream_t)s, partial, nparts, c, 2,
