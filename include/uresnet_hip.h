@@ -117,6 +117,19 @@ int ur_conv1x1_pw_dgrad_pair(const void* dy, const float* w, int w_cout, int w_c
 int ur_conv1x1_pw_wgrad_affine_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
                                     const float* aff_b, int x_relu, const void* dy, float* dw, void* workspace, size_t ws_bytes,
                                     const ur_conv_desc* d, ur_stream_t s);
+/* ur_conv1x1_pw_wgrad_affine_pair for a head whose input is relu(BatchNorm(cat)) in training mode (S/C:127-133 over S/C:280),
+ * which also returns that BatchNorm's backward sums, so that ur_bn_act_bwd_reduce over the input gradient is not needed.
+ * The kernel multiplies dy with the ReLU mask and with mask * xhat instead of with the activated input:
+ *   S1[co][c] = sum_p dy[p][co] open[p][c], S2[co][c] = sum_p dy[p][co] open[p][c] xhat[p][c];
+ *   dw[co][c] = gamma[c] S2 + beta[c] S1 ([w_cout][ca + cb], may be NULL);
+ *   sums[c] = (sum_co W[co][c] S1, sum_co W[co][c] S2) = (sum g, sum g xhat), also written to dbeta / dgamma (may be NULL),
+ * with W rounded to bf16 as ur_conv1x1_pw_dgrad_pair used it.  mean, invstd, gamma, beta: [ca + cb] fp32; aff_a / aff_b: the
+ * folded constants of the forward call (the mask is the forward's); w: [w_cout][ca + cb] fp32. */
+size_t ur_conv1x1_pw_wgrad_bn_workspace(const ur_conv_desc* d);
+int ur_conv1x1_pw_wgrad_bn_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
+                                const float* aff_b, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const void* dy, const float* w, int w_cout, float* dw, float* sums, float* dgamma, float* dbeta,
+                                void* workspace, size_t ws_bytes, const ur_conv_desc* d, ur_stream_t s);
 
 /* ---------------------------------------------------------------- 3x3 / stride 1 / pad 1, bf16: LDS-tiled kernel
  * Same contract as ur_conv2d_fwd / ur_conv2d_dgrad for the layers that carry ~94 % of the FLOPs

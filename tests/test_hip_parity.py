@@ -1847,11 +1847,71 @@ def test_head_over_the_two_branch_outputs_matches_the_head_over_their_concatenat
         assert rel_l2(p[0], r[0]) < 1e-3
         assert rel_l2(p[1], r[1]) < 2e-3 and rel_l2(p[2], r[2]) < 2e-3
         for k in r[3]:
-            assert rel_l2(p[3][k].cpu(), r[3][k].cpu()) < 2e-3, k
+            # (sums of 80 k signed bf16-rounded terms: each path stands 1.5-1.9e-3 from a float64 evaluation, independently)
+            assert rel_l2(p[3][k].cpu(), r[3][k].cpu()) < 4e-3, k
         for k in r[4]:
             assert torch.allclose(r[4][k].float(), p[4][k].float(), rtol=1e-5, atol=1e-6), k
         if not train_mode:                  # no statistics pass: the same constants, the same products in the same order
             assert torch.equal(p[0], r[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ca,cb,h,w,classes", [(2, 64, 16, 256, 160, 19), (1, 64, 16, 301, 219, 19), (2, 8, 16, 200, 170, 5),
+                                                 (1, 32, 24, 263, 251, 8)])
+def test_head_batchnorm_backward_sums_from_the_backward_weight_kernel(pkg, n, ca, cb, h, w, classes):
+    """The pair head's backward with the BatchNorm sums (sum g, sum g * xhat) and the weight gradient both derived from the two
+    products dy^T * mask and dy^T * (mask * xhat) of one streaming kernel (ur_conv1x1_pw_wgrad_bn_pair) against the separate
+    passes (ur_conv1x1_pw_wgrad_affine_pair + ur_bn_act_bwd_reduce over each half).  Each of the sums is a sum of ~10^5
+    signed terms with one bf16 rounding per term (the input gradient in the separate pass, xhat in the fused one, the
+    activation in the plain weight gradient), so either path stands 1.3-1.9e-3 from a float64 evaluation of the formulas on
+    the stored tensors (asserted at 3e-3) and the two paths 2.4e-3 from each other (4e-3); the fused BatchNorm bias gradient
+    has no rounded factor (mask values are exact) and matches float64 to 1e-5; both input gradients to 1e-3; the two
+    reduction passes are gone."""
+    ops, B = pkg.ops, pkg.modules._blocks
+    torch.manual_seed(11)
+    head = B.OutConv(ca + cb, classes).to(DEV).train()
+    with torch.no_grad():
+        head[0].weight.uniform_(0.5, 1.5); head[0].bias.uniform_(-0.3, 0.3)
+    a0 = torch.randn(n, ca, h, w, device=DEV) * 2 + 0.3
+    b0 = torch.randn(n, cb, h, w, device=DEV) * 0.7 - 0.2
+    g0 = torch.randn(n, classes, h, w, device=DEV)
+    state = {k: v.clone() for k, v in head.state_dict().items()}
+
+    def run(fused):
+        old, ops.fuse_head_bn_sums = ops.fuse_head_bn_sums, fused
+        try:
+            head.load_state_dict(state)
+            head.zero_grad(set_to_none=True)
+            xa = ops.as_activation(a0, torch.bfloat16).detach().requires_grad_(True)
+            xb = ops.as_activation(b0, torch.bfloat16).detach().requires_grad_(True)
+            out = ops.bn_relu_conv1x1_pair(xa, xb, head[0], head[2])
+            assert out is not None
+            ops.kernel_timings, ops.kernel_timing_tags = [], {"hbm:bn_bwd_reduce"}
+            out.backward(ops.as_activation(g0, torch.bfloat16))
+            passes = len(ops.kernel_timings)
+            return (host(pkg, xa.grad), host(pkg, xb.grad), {k: p.grad.clone().cpu() for k, p in head.named_parameters()}, passes,
+                    host(pkg, xa), host(pkg, xb))
+        finally:
+            ops.fuse_head_bn_sums, ops.kernel_timings, ops.kernel_timing_tags = old, None, None
+
+    r, f = run(False), run(True)
+    assert r[3] == 2 and f[3] == 0
+    assert rel_l2(f[0], r[0]) < 1e-3 and rel_l2(f[1], r[1]) < 1e-3
+    assert rel_l2(f[2]["0.weight"], r[2]["0.weight"]) < 4e-3 and rel_l2(f[2]["0.bias"], r[2]["0.bias"]) < 3e-3
+    assert rel_l2(f[2]["2.weight"], r[2]["2.weight"]) < 4e-3
+    assert torch.equal(f[2]["2.bias"], r[2]["2.bias"])
+    # float64 evaluation from the stored (bf16) tensors: x = cat of the two inputs, statistics of the batch
+    x = torch.cat([f[4], f[5]], 1).double()
+    gq = g0.to(torch.bfloat16).double().cpu()
+    m, v = x.mean((0, 2, 3), keepdim=True), x.var((0, 2, 3), unbiased=False, keepdim=True)
+    xh = (x - m) / (v + 1e-5).sqrt()
+    ga, be = state["0.weight"].double().cpu().view(1, -1, 1, 1), state["0.bias"].double().cpu().view(1, -1, 1, 1)
+    act = (ga * xh + be).clamp_min(0)
+    wq = state["2.weight"].to(torch.bfloat16).double().cpu().view(classes, ca + cb)
+    g = torch.einsum("nohw,oc->nchw", gq, wq) * (act > 0)
+    assert rel_l2(f[2]["0.bias"].double(), g.sum((0, 2, 3))) < 1e-5
+    assert rel_l2(f[2]["0.weight"].double(), (g * xh).sum((0, 2, 3))) < 3e-3
+    assert rel_l2(f[2]["2.weight"].double().view(classes, -1), torch.einsum("nohw,nchw->oc", gq, act)) < 3e-3
 
 
 @pytest.mark.gpu
@@ -1883,6 +1943,12 @@ def test_two_branch_model_without_the_merged_tensor_matches_the_model_with_it(pk
     assert abs(a[0] - b[0]) < 2e-3 * abs(a[0])
     assert rel_l2(b[1], a[1]) < 5e-3
     for k in a[2]:
+        if k in ("Upsample.pwc.0.bias", "up4.conv.4.weight"):
+            # Gradients that are zero by construction: a bias in front of a training-mode BatchNorm (the sum of that BatchNorm's
+            # input gradient), and the scale of a BatchNorm with zero shift whose ReLU output feeds another BatchNorm (scale
+            # invariance).  What both runs hold is rounding residue (1e-6 against 1e-2 for the other parameters).
+            assert a[2][k].abs().max() < 1e-4 and b[2][k].abs().max() < 1e-4
+            continue
         assert rel_l2(b[2][k], a[2][k]) < 5e-2, k
 
 

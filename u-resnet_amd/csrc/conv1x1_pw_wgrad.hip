@@ -32,6 +32,8 @@ struct PwWgParams {
     // x as two dense tensors (a channel concatenation that was never materialised): channels [K1, K) come from x2 (pitch
     // ld_x2, constants x_aff2 = [2][K - K1]) when x2 is set; K1 is a multiple of 8
     const bf16_t* x2; int K1, ld_x2; const float* x_aff2;
+    // BNS: [K] batch mean and inverse standard deviation of the BatchNorm folded into x_aff (both tensors' channels in order)
+    const float* bn_mean; const float* bn_invstd;
 };
 
 // x -> bf16(max(x * scale + shift, 0)) on 8 consecutive channels; cs = the channels' scales in LDS, their shifts K floats on
@@ -55,13 +57,39 @@ int odd_pitch(int bytes) {
     return q * 16;
 }
 
+// BNS: x -> the two operands from which both the weight gradient and the BatchNorm's backward sums follow.  With
+// a = relu(gamma * xhat + beta) the input of the convolution and open = (a > 0):
+//   S1[co][c] = sum_p dy[p][co] * open[p][c],   S2[co][c] = sum_p dy[p][co] * open[p][c] * xhat[p][c]
+//   dW[co][c] = gamma[c] * S2 + beta[c] * S1;   sum_p g[p][c] = sum_co W[co][c] * S1,   sum_p g * xhat = sum_co W[co][c] * S2
+// (g = the convolution's input gradient masked by the ReLU) -- the reduction pass of the BatchNorm backward, which would read
+// the input gradient and x again, is not needed.  cs: scale, shift (the forward's folded constants: same mask), then
+// invstd and -mean * invstd, K floats apart.
+__device__ __forceinline__ void pw_bns8(const bf16x8_t& v, const float* cs, int K, bf16x8_t& open, bf16x8_t& openxh) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 sc = *reinterpret_cast<const float4*>(cs + 4 * h), sh = *reinterpret_cast<const float4*>(cs + K + 4 * h);
+        const float4 xs = *reinterpret_cast<const float4*>(cs + 2 * K + 4 * h), xo = *reinterpret_cast<const float4*>(cs + 3 * K + 4 * h);
+        const float a[4] = {sc.x, sc.y, sc.z, sc.w}, b[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float c[4] = {xs.x, xs.y, xs.z, xs.w}, d[4] = {xo.x, xo.y, xo.z, xo.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = (float)v[4 * h + e];
+            const bool on = fmaf(x, a[e], b[e]) > 0.f;
+            open[4 * h + e] = (bf16_t)(on ? 1.f : 0.f);
+            openxh[4 * h + e] = (bf16_t)(on ? fmaf(x, c[e], d[e]) : 0.f);
+        }
+    }
+}
+
 // MB / KB = 16-channel blocks of dy / x that the instantiation covers (M <= 16 MB, K <= 16 KB; rows beyond M or K are zero)
-template <int MB, int KB, bool AFF>
+template <int MB, int KB, bool AFF, bool BNS = false>
 __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
+    static_assert(!BNS || AFF, "the BatchNorm sums need the folded constants");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned char* xt = lds + (size_t)wave * 32 * (p.pitch_x + p.pitch_y);
-    unsigned char* yt = xt + 32 * p.pitch_x;
+    constexpr int NX = BNS ? 2 : 1;                        // x tiles per wave: BNS stages `open` and `open * xhat`
+    unsigned char* xt = lds + (size_t)wave * 32 * (NX * p.pitch_x + p.pitch_y);
+    unsigned char* yt = xt + NX * 32 * p.pitch_x;
     const float* aff = reinterpret_cast<const float*>(lds + p.aff_off);
     if constexpr (AFF) {
         float* a = const_cast<float*>(aff);
@@ -69,6 +97,13 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
         for (int i = threadIdx.x; i < 2 * p.K; i += NT) {
             const int which = i >= p.K ? 1 : 0, c = i - which * p.K;
             a[i] = c < ka ? p.x_aff[which * ka + c] : p.x_aff2[which * (p.K - ka) + c - ka];
+        }
+        if constexpr (BNS) {
+            for (int c = threadIdx.x; c < p.K; c += NT) {
+                const float is = p.bn_invstd[c];
+                a[2 * p.K + c] = is;
+                a[3 * p.K + c] = -p.bn_mean[c] * is;
+            }
         }
         __syncthreads();
     }
@@ -106,11 +141,14 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
         return __builtin_bit_cast(bf16x8_t, both);
     };
 
-    f32x4_t acc[MB][KB];
+    f32x4_t acc[MB][KB], acc2[BNS ? MB : 1][BNS ? KB : 1];
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-        for (int b = 0; b < KB; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < KB; ++b) {
+            acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BNS) acc2[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 
     const long long chunks = (p.P + 31) / 32;
     const long long step = (long long)gridDim.x * (NT / 64);
@@ -130,7 +168,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
             yv[i] = ypix[i] < live ? *reinterpret_cast<const bf16x8_t*>(yb + ysrc[i]) : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
     };
     // channel groups beyond K / M inside the last 16-channel block are never written: zero the tiles once
-    for (int i = lane; i < 32 * (p.pitch_x + p.pitch_y) / 16; i += 64)
+    for (int i = lane; i < 32 * (NX * p.pitch_x + p.pitch_y) / 16; i += 64)
         *reinterpret_cast<bf16x8_t*>(xt + i * 16) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
     if (c < chunks) fetch(c);
     for (; c < chunks; c += step) {
@@ -139,7 +177,12 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
 #pragma unroll
         for (int i = 0; i < XL; ++i)
             if (xpix[i] < 32) {
-                if constexpr (AFF) *reinterpret_cast<bf16x8_t*>(xt + xlds[i]) = pw_affine8(xv[i], aff + xch[i], p.K, p.x_relu);
+                if constexpr (BNS) {
+                    bf16x8_t o1, o2;
+                    pw_bns8(xv[i], aff + xch[i], p.K, o1, o2);
+                    *reinterpret_cast<bf16x8_t*>(xt + xlds[i]) = o1;
+                    *reinterpret_cast<bf16x8_t*>(xt + 32 * p.pitch_x + xlds[i]) = o2;
+                } else if constexpr (AFF) *reinterpret_cast<bf16x8_t*>(xt + xlds[i]) = pw_affine8(xv[i], aff + xch[i], p.K, p.x_relu);
                 else *reinterpret_cast<bf16x8_t*>(xt + xlds[i]) = xv[i];
             }
 #pragma unroll
@@ -156,29 +199,73 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(PwWgParams p) {
             const bf16x8_t bf = frag(xr + b * 32, 4 * p.pitch_x);
 #pragma unroll
             for (int a = 0; a < MB; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf, acc[a][b], 0, 0, 0);
+            if constexpr (BNS) {
+                const bf16x8_t bf2 = frag(xr + 32 * p.pitch_x + b * 32, 4 * p.pitch_x);
+#pragma unroll
+                for (int a = 0; a < MB; ++a) acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf2, acc2[a][b], 0, 0, 0);
+            }
         }
     }
 
     // ---- the four waves' blocks, summed in wave order, -> one slab per workgroup ------------------------------------------
     float* red = reinterpret_cast<float*>(lds);
     constexpr int NOUT = MB * 16 * KB * 16;
-    for (int w = 0; w < NT / 64; ++w) {
-        __syncthreads();
-        if (wave == w) {
+    float* slab = p.ws + (size_t)blockIdx.x * NOUT * NX;       // BNS: S1 then S2
 #pragma unroll
-            for (int a = 0; a < MB; ++a)
+    for (int which = 0; which < NX; ++which) {
+        for (int w = 0; w < NT / 64; ++w) {
+            __syncthreads();
+            if (wave == w) {
 #pragma unroll
-                for (int b = 0; b < KB; ++b)
+                for (int a = 0; a < MB; ++a)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int idx = (a * 16 + 4 * g + i) * (KB * 16) + b * 16 + li;
-                        red[idx] = (w == 0 ? 0.f : red[idx]) + acc[a][b][i];
-                    }
+                    for (int b = 0; b < KB; ++b)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int idx = (a * 16 + 4 * g + i) * (KB * 16) + b * 16 + li;
+                            float v = acc[a][b][i];
+                            if constexpr (BNS) { if (which == 1) v = acc2[a][b][i]; }
+                            red[idx] = (w == 0 ? 0.f : red[idx]) + v;
+                        }
+            }
         }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NOUT; i += NT) slab[which * NOUT + i] = red[i];
     }
-    __syncthreads();
-    float* slab = p.ws + (size_t)blockIdx.x * NOUT;
-    for (int i = threadIdx.x; i < NOUT; i += NT) slab[i] = red[i];
+}
+
+// raw[i] = sum_s ws[s][i] over the slabs (fixed order)
+template <int SL>
+__global__ __launch_bounds__(256) void pw_slab_sum_kernel(const float* __restrict__ ws, float* __restrict__ raw, long long per, int nslab) {
+    long long idx;
+    float t;
+    if (ur_slab_sum<SL>(ws, per, nslab, idx, t)) raw[idx] = t;
+}
+
+// From S1, S2 ([rows][cols] each, see pw_bns8): the weight gradient dw[co][ci] (co < w_cout, ci < w_cin) and, per input
+// channel, the BatchNorm's backward sums (sum g, sum g * xhat) = (dbeta, dgamma).  The weight enters rounded to bf16, as the
+// backward-data kernel that produced g used it.
+__global__ __launch_bounds__(256) void pw_wgrad_bn_finalize_kernel(const float* __restrict__ raw, int rows, int cols,
+                                                                   const float* __restrict__ w, int w_cout, int w_cin,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ dw, float* __restrict__ sums,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= w_cin) return;
+    const float* s1 = raw;
+    const float* s2 = raw + (size_t)rows * cols;
+    const float ga = gamma[c], be = beta[c];
+    float g0 = 0.f, g1 = 0.f;
+    for (int o = 0; o < w_cout; ++o) {
+        const float a = s1[(size_t)o * cols + c], b = s2[(size_t)o * cols + c];
+        if (dw) dw[(size_t)o * w_cin + c] = ga * b + be * a;
+        const float wq = (float)(bf16_t)w[(size_t)o * w_cin + c];
+        g0 = fmaf(wq, a, g0);
+        g1 = fmaf(wq, b, g1);
+    }
+    sums[(size_t)c * 2] = g0; sums[(size_t)c * 2 + 1] = g1;
+    if (dbeta) dbeta[c] = g0;
+    if (dgamma) dgamma[c] = g1;
 }
 
 // dw[co][ci] = sum_s ws[s][co][ci] over the [16 MB][16 KB] slabs (co < w_cout, ci < w_cin are written)
@@ -208,8 +295,8 @@ bool pick(const ur_conv_desc* d, Cfg& c) {
 }
 
 // LDS rows hold whole 16-channel blocks (the transposing reads fetch them whole; channels beyond K / M stay zero)
-size_t lds_bytes(const Cfg& c) {
-    const size_t stage = (size_t)(NT / 64) * 32 * (odd_pitch(c.kb * 32) + odd_pitch(c.mb * 32));
+size_t lds_bytes(const Cfg& c, int nx = 1) {
+    const size_t stage = (size_t)(NT / 64) * 32 * (nx * odd_pitch(c.kb * 32) + odd_pitch(c.mb * 32));
     const size_t red = (size_t)c.mb * 16 * c.kb * 16 * sizeof(float);
     return stage > red ? stage : red;
 }
@@ -237,17 +324,26 @@ size_t ur_conv1x1_pw_wgrad_workspace(const ur_conv_desc* d) {
     return (size_t)PW_WG_GRID_MAX * c.mb * 16 * c.kb * 16 * sizeof(float);
 }
 
+// ur_conv1x1_pw_wgrad_bn_pair: two slabs per workgroup and the summed pair behind them
+size_t ur_conv1x1_pw_wgrad_bn_workspace(const ur_conv_desc* d) {
+    Cfg c;
+    if (!shape_ok(d) || !pick(d, c)) return 0;
+    return (size_t)(PW_WG_GRID_MAX + 1) * 2 * c.mb * 16 * c.kb * 16 * sizeof(float);
+}
+
 }  // extern "C"
 
 namespace {
 struct PwWgSecond { const void* x2; int k1, ld_x2; const float* aff2; };
+struct PwWgBn { const float *mean, *invstd, *gamma, *beta, *w; int w_cout, w_cin; float *sums, *dgamma, *dbeta; };
 int pw_wgrad_launch(const void* x, const float* x_aff, int x_relu, const void* dy, float* dw, void* workspace, size_t ws_bytes,
-                    const ur_conv_desc* d, ur_stream_t s, const PwWgSecond* second = nullptr) {
+                    const ur_conv_desc* d, ur_stream_t s, const PwWgSecond* second = nullptr, const PwWgBn* bn = nullptr) {
     Cfg c;
     UR_REQUIRE(shape_ok(d) && pick(d, c), "conv1x1_pw_wgrad: needs bf16, 1x1 stride 1, 8 | channels and pitches, cout <= 32, cin <= 96");
-    UR_REQUIRE(x && dy && dw && workspace, "conv1x1_pw_wgrad: null pointer");
+    UR_REQUIRE(x && dy && (dw || bn) && workspace, "conv1x1_pw_wgrad: null pointer");
     UR_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv1x1_pw_wgrad: tensors must be 16-byte aligned");
-    UR_REQUIRE(ws_bytes >= ur_conv1x1_pw_wgrad_workspace(d), "conv1x1_pw_wgrad: workspace too small");
+    UR_REQUIRE(ws_bytes >= (bn ? ur_conv1x1_pw_wgrad_bn_workspace(d) : ur_conv1x1_pw_wgrad_workspace(d)), "conv1x1_pw_wgrad: workspace too small");
+    UR_REQUIRE(!bn || x_aff, "conv1x1_pw_wgrad: the BatchNorm sums need the folded constants");
     PwWgParams p{};
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.ws = (float*)workspace;
     p.P = (long long)d->n * d->h * d->w;
@@ -261,19 +357,21 @@ int pw_wgrad_launch(const void* x, const float* x_aff, int x_relu, const void* d
                    "conv1x1_pw_wgrad: the two-tensor input needs 8 | channel split and pitch, 16-byte alignment and constants for both");
         p.x2 = (const bf16_t*)second->x2; p.K1 = second->k1; p.ld_x2 = second->ld_x2; p.x_aff2 = second->aff2;
     }
-    size_t lds = lds_bytes(c);
+    size_t lds = lds_bytes(c, bn ? 2 : 1);
     if (x_aff) {                                   // the input's constants sit behind the staging rows / sum buffer
         lds = (lds + 15) / 16 * 16;
         p.x_aff = x_aff; p.x_relu = x_relu; p.aff_off = (int)lds;
-        lds += (size_t)2 * p.K * sizeof(float);
+        lds += (size_t)(bn ? 4 : 2) * p.K * sizeof(float);
     }
+    if (bn) { p.bn_mean = bn->mean; p.bn_invstd = bn->invstd; }
     const long long chunks = (p.P + 31) / 32;
     int grid = pw_wg_grid() < PW_WG_GRID_MAX ? pw_wg_grid() : PW_WG_GRID_MAX;
     if (chunks < (long long)grid * (NT / 64)) grid = (int)((chunks + NT / 64 - 1) / (NT / 64));
     hipStream_t st = (hipStream_t)s;
 #define UR_PW_WG(MB, KB)                                                                                  \
     do {                                                                                                  \
-        if (x_aff) hipLaunchKernelGGL((pw_wgrad_kernel<MB, KB, true>), dim3(grid), dim3(NT), lds, st, p); \
+        if (bn) hipLaunchKernelGGL((pw_wgrad_kernel<MB, KB, true, true>), dim3(grid), dim3(NT), lds, st, p); \
+        else if (x_aff) hipLaunchKernelGGL((pw_wgrad_kernel<MB, KB, true>), dim3(grid), dim3(NT), lds, st, p); \
         else hipLaunchKernelGGL((pw_wgrad_kernel<MB, KB, false>), dim3(grid), dim3(NT), lds, st, p);      \
     } while (0)
     if (c.mb == 1) UR_PW_WG(1, 2);
@@ -284,6 +382,17 @@ int pw_wgrad_launch(const void* x, const float* x_aff, int x_relu, const void* d
     if (int e = ur_check_launch("conv1x1_pw_wgrad")) return e;
     const int rows = c.mb * 16, cols = c.kb * 16;
     const long long per = (long long)rows * cols;
+    if (bn) {
+        float* raw = p.ws + (size_t)PW_WG_GRID_MAX * 2 * per;
+        if (ur_slab_lanes(grid) == 32)
+            hipLaunchKernelGGL(pw_slab_sum_kernel<32>, dim3(ur_slab_grid(2 * per, 32)), dim3(256), 0, st, p.ws, raw, 2 * per, grid);
+        else
+            hipLaunchKernelGGL(pw_slab_sum_kernel<8>, dim3(ur_slab_grid(2 * per, 8)), dim3(256), 0, st, p.ws, raw, 2 * per, grid);
+        if (int e = ur_check_launch("conv1x1_pw_wgrad_slab_sum")) return e;
+        hipLaunchKernelGGL(pw_wgrad_bn_finalize_kernel, dim3(ur_cdiv(bn->w_cin, 256)), dim3(256), 0, st, raw, rows, cols, bn->w,
+                           bn->w_cout, bn->w_cin, bn->gamma, bn->beta, dw, bn->sums, bn->dgamma, bn->dbeta);
+        return ur_check_launch("conv1x1_pw_wgrad_bn_finalize");
+    }
     if (ur_slab_lanes(grid) == 32)
         hipLaunchKernelGGL(pw_wgrad_reduce_kernel<32>, dim3(ur_slab_grid(per, 32)), dim3(256), 0, st, p.ws, dw, rows, cols, d->cout,
                            d->cin, grid);
@@ -317,6 +426,22 @@ int ur_conv1x1_pw_wgrad_affine_pair(const void* xa, int ca, int ld_a, const void
     UR_REQUIRE(da.in_ld % 8 == 0 && da.in_ld >= ca, "conv1x1_pw_wgrad_affine_pair: bad pitch of the first tensor");
     const PwWgSecond second{xb, ca, ld_b ? ld_b : cb, aff_b};
     return pw_wgrad_launch(xa, aff_a, x_relu, dy, dw, workspace, ws_bytes, &da, s, &second);
+}
+
+
+int ur_conv1x1_pw_wgrad_bn_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
+                                const float* aff_b, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const void* dy, const float* w, int w_cout, float* dw, float* sums, float* dgamma, float* dbeta,
+                                void* workspace, size_t ws_bytes, const ur_conv_desc* d, ur_stream_t s) {
+    UR_REQUIRE(xa && xb && aff_a && aff_b && mean && invstd && gamma && beta && w && sums && d, "conv1x1_pw_wgrad_bn_pair: null argument");
+    UR_REQUIRE(ca + cb == d->cin, "conv1x1_pw_wgrad_bn_pair: %d + %d channels against a descriptor of %d", ca, cb, d->cin);
+    UR_REQUIRE(w_cout > 0 && w_cout <= d->cout, "conv1x1_pw_wgrad_bn_pair: %d weight rows against a descriptor of %d", w_cout, d->cout);
+    ur_conv_desc da = *d;
+    da.in_ld = ld_a ? ld_a : ca;
+    UR_REQUIRE(da.in_ld % 8 == 0 && da.in_ld >= ca, "conv1x1_pw_wgrad_bn_pair: bad pitch of the first tensor");
+    const PwWgSecond second{xb, ca, ld_b ? ld_b : cb, aff_b};
+    const PwWgBn bn{mean, invstd, gamma, beta, w, w_cout, d->cin, sums, dgamma, dbeta};
+    return pw_wgrad_launch(xa, aff_a, 1, dy, dw, workspace, ws_bytes, &da, s, &second, &bn);      // (dw may be null)
 }
 
 }  // extern "C"

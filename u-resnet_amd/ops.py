@@ -1226,7 +1226,23 @@ class _BNReluConv1x1Pair(Function):
         with _Timed("pw_dgrad", _conv_flops(d), d):
             call("ur_conv1x1_pw_dgrad_pair", dz.data_ptr(), weight.data_ptr(), cout, c, da[0].data_ptr(), ca, ca, da[1].data_ptr(),
                  cb, cb, C.byref(d), _stream())
-        if ctx.needs_input_grad[10]:
+        dgamma, dbeta = grad_buffer(gamma), grad_buffer(beta)
+        off = lambda t, o: t.data_ptr() + 4 * o      # noqa: E731
+        all_sums = None
+        if fuse_head_bn_sums and not ctx.eval:
+            # the backward-weight kernel multiplies the gradient with the ReLU mask and with mask * xhat: the weight gradient
+            # and the BatchNorm's backward sums both follow from those two products (ur_conv1x1_pw_wgrad_bn_pair), and the
+            # reduction passes over (da, ya) and (db, yb) are not needed
+            all_sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
+            if ctx.needs_input_grad[10]:
+                dw = grad_buffer(weight)
+            ws = _workspace(query("ur_conv1x1_pw_wgrad_bn_workspace", C.byref(d)), dev)
+            with _Timed("pw_wgrad", 2 * _conv_flops(d), d):
+                call("ur_conv1x1_pw_wgrad_bn_pair", ya.data_ptr(), ca, ca, yb.data_ptr(), cb, cb, aff_a.data_ptr(), aff_b.data_ptr(),
+                     mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dz.data_ptr(), weight.data_ptr(), cout,
+                     _p(dw), all_sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(d),
+                     _stream())
+        elif ctx.needs_input_grad[10]:
             dw = grad_buffer(weight, (d.cout, c, 1, 1))
             ws = _workspace(query("ur_conv1x1_pw_wgrad_workspace", C.byref(d)), dev)
             with _Timed("pw_wgrad", _conv_flops(d), d):
@@ -1234,18 +1250,19 @@ class _BNReluConv1x1Pair(Function):
                      aff_b.data_ptr(), 1, dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(d), _stream())
             if d.cout != cout:
                 dw = dw[:cout].contiguous()
-        dgamma, dbeta = grad_buffer(gamma), grad_buffer(beta)
-        off = lambda t, o: t.data_ptr() + 4 * o      # noqa: E731
         dys = []
         for y, g, o, ci in ((ya, da[0], 0, ca), (yb, da[1], ca, cb)):
             tb = y.numel() * y.element_size()
-            partial = torch.empty((query("ur_bn_stats_rows", rows, ci), ci, 2), dtype=torch.float32, device=dev)
-            with _Timed("hbm:bn_bwd_reduce", tb * 2):
-                call("ur_bn_act_bwd_reduce", g.data_ptr(), y.data_ptr(), None, off(mean, o), off(invstd, o), off(gamma, o),
-                     off(beta, o), _lib.ACT_RELU, _dt(y), rows, ci, ci, partial.data_ptr(), _stream())
-            sums = torch.empty((ci, 2), dtype=torch.float32, device=dev)
-            call("ur_bn_bwd_finalize", partial.data_ptr(), partial.shape[0], ci, sums.data_ptr(), off(dgamma, o), off(dbeta, o),
-                 _stream())
+            if all_sums is not None:
+                sums = all_sums[o:o + ci]
+            else:
+                partial = torch.empty((query("ur_bn_stats_rows", rows, ci), ci, 2), dtype=torch.float32, device=dev)
+                with _Timed("hbm:bn_bwd_reduce", tb * 2):
+                    call("ur_bn_act_bwd_reduce", g.data_ptr(), y.data_ptr(), None, off(mean, o), off(invstd, o), off(gamma, o),
+                         off(beta, o), _lib.ACT_RELU, _dt(y), rows, ci, ci, partial.data_ptr(), _stream())
+                sums = torch.empty((ci, 2), dtype=torch.float32, device=dev)
+                call("ur_bn_bwd_finalize", partial.data_ptr(), partial.shape[0], ci, sums.data_ptr(), off(dgamma, o), off(dbeta, o),
+                     _stream())
             dy = torch.empty_like(y, memory_format=CL)
             with _Timed("hbm:bn_bwd_apply", tb * 3):
                 call("ur_bn_act_bwd_apply", g.data_ptr(), y.data_ptr(), None, off(mean, o), off(invstd, o), off(gamma, o),
@@ -1256,6 +1273,7 @@ class _BNReluConv1x1Pair(Function):
 
 
 fuse_merge_into_head = os.environ.get("URESNET_MERGE_PAIR", "1") != "0"    # False: the Feature Merge builds the merged tensor
+fuse_head_bn_sums = os.environ.get("URESNET_HEAD_BN_SUMS", "1") != "0"    # False: the head's BatchNorm backward reduces over its input gradient
 
 
 def bn_relu_conv1x1_pair_supported(n, ca, cb, h, w, dtype, bn, conv):
