@@ -126,6 +126,11 @@ int ur_conv1x1_pw_wgrad_affine_pair(const void* xa, int ca, int ld_a, const void
  * with W rounded to bf16 as ur_conv1x1_pw_dgrad_pair used it.  mean, invstd, gamma, beta: [ca + cb] fp32; aff_a / aff_b: the
  * folded constants of the forward call (the mask is the forward's); w: [w_cout][ca + cb] fp32. */
 size_t ur_conv1x1_pw_wgrad_bn_workspace(const ur_conv_desc* d);
+/* the same over one input tensor (x, pitch d->in_ld): the backward of ur_conv1x1_pw_fwd_affine in training mode (the EUCB*
+ * projection behind its last BatchNorm+ReLU, S/C:84-86) */
+int ur_conv1x1_pw_wgrad_bn(const void* x, const float* x_aff, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, const void* dy, const float* w, int w_cout, float* dw, float* sums, float* dgamma,
+                           float* dbeta, void* workspace, size_t ws_bytes, const ur_conv_desc* d, ur_stream_t s);
 int ur_conv1x1_pw_wgrad_bn_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
                                 const float* aff_b, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 const void* dy, const float* w, int w_cout, float* dw, float* sums, float* dgamma, float* dbeta,

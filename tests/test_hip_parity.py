@@ -1915,6 +1915,44 @@ def test_head_batchnorm_backward_sums_from_the_backward_weight_kernel(pkg, n, ca
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,c,h,w,cout,window", [(2, 80, 256, 160, 19, False), (2, 32, 200, 170, 16, True), (1, 24, 263, 251, 8, False)])
+def test_single_tensor_head_batchnorm_backward_sums_from_the_backward_weight_kernel(pkg, n, c, h, w, cout, window):
+    """ops.bn_relu_conv1x1 (segmentation head over one tensor, S/C:127-133; EUCB* projection, S/C:84-86): backward with the
+    BatchNorm sums taken from the backward-weight kernel (ur_conv1x1_pw_wgrad_bn) against the separate reduction pass, the
+    output gradient also as a channel window of a wider tensor.  Tolerances as in the two-tensor test above."""
+    ops, hnn = pkg.ops, pkg.nn
+    torch.manual_seed(3)
+    bn, conv = hnn.BatchNorm2d(c).to(DEV).train(), hnn.Conv2d(c, cout, kernel_size=1).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    y0 = torch.randn(n, c, h, w, device=DEV) * 1.5 + 0.2
+    wide = 80 if window else cout
+    g0 = torch.randn(n, wide, h, w, device=DEV)
+
+    def run(fused):
+        old, ops.fuse_head_bn_sums = ops.fuse_head_bn_sums, fused
+        try:
+            for m in (bn, conv):
+                m.zero_grad(set_to_none=True)
+            y = ops.as_activation(y0, torch.bfloat16).detach().requires_grad_(True)
+            out = ops.bn_relu_conv1x1(y, bn, conv)
+            assert out is not None
+            g = ops.as_activation(g0, torch.bfloat16)
+            ops.kernel_timings, ops.kernel_timing_tags = [], {"hbm:bn_bwd_reduce"}
+            out.backward(ops.alias_window(g, 64, cout) if window else g)
+            passes = len(ops.kernel_timings)
+            return host(pkg, y.grad), [p.grad.clone().cpu() for p in (bn.weight, bn.bias, conv.weight, conv.bias)], passes
+        finally:
+            ops.fuse_head_bn_sums, ops.kernel_timings, ops.kernel_timing_tags = old, None, None
+
+    r, f = run(False), run(True)
+    assert r[2] == 1 and f[2] == 0
+    assert rel_l2(f[0], r[0]) < 1e-3
+    assert rel_l2(f[1][0], r[1][0]) < 4e-3 and rel_l2(f[1][1], r[1][1]) < 3e-3 and rel_l2(f[1][2], r[1][2]) < 4e-3
+    assert torch.equal(f[1][3], r[1][3])
+
+
+@pytest.mark.gpu
 def test_two_branch_model_without_the_merged_tensor_matches_the_model_with_it(pkg):
     """UResNetNewEUCB (S/C:214-345) with the Feature Merge read as two tensors by the head against the same model writing
     both branches into one 80-channel tensor: loss and every gradient after one backward pass agree to bf16 rounding."""

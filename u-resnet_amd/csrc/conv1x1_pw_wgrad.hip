@@ -429,6 +429,15 @@ int ur_conv1x1_pw_wgrad_affine_pair(const void* xa, int ca, int ld_a, const void
 }
 
 
+int ur_conv1x1_pw_wgrad_bn(const void* x, const float* x_aff, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, const void* dy, const float* w, int w_cout, float* dw, float* sums, float* dgamma,
+                           float* dbeta, void* workspace, size_t ws_bytes, const ur_conv_desc* d, ur_stream_t s) {
+    UR_REQUIRE(x && x_aff && mean && invstd && gamma && beta && w && sums && d, "conv1x1_pw_wgrad_bn: null argument");
+    UR_REQUIRE(w_cout > 0 && w_cout <= d->cout, "conv1x1_pw_wgrad_bn: %d weight rows against a descriptor of %d", w_cout, d->cout);
+    const PwWgBn bn{mean, invstd, gamma, beta, w, w_cout, d->cin, sums, dgamma, dbeta};
+    return pw_wgrad_launch(x, x_aff, 1, dy, dw, workspace, ws_bytes, d, s, nullptr, &bn);      // (dw may be null)
+}
+
 int ur_conv1x1_pw_wgrad_bn_pair(const void* xa, int ca, int ld_a, const void* xb, int cb, int ld_b, const float* aff_a,
                                 const float* aff_b, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 const void* dy, const float* w, int w_cout, float* dw, float* sums, float* dgamma, float* dbeta,

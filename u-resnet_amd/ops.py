@@ -1030,8 +1030,10 @@ class _BNReluConv1x1(Function):
     """conv1x1(relu(BatchNorm(y))) (+bias) without the normalised tensor: the streaming 1x1 kernels apply the folded
     BatchNorm (one multiply-add per element, then ReLU) to every piece of y on its way into their LDS rows -- forward
     (ur_conv1x1_pw_fwd_affine) and backward-weight (ur_conv1x1_pw_wgrad_affine), the two kernels that read the activated
-    tensor.  Backward-data yields the gradient of the activated tensor, from which the usual two BatchNorm-backward passes
-    (mask rebuilt from y) produce dy.  Saves one pass over the tensor in forward (read y, write a) and the tensor itself."""
+    tensor.  Backward-data yields the gradient of the activated tensor; the BatchNorm's backward sums come out of the
+    backward-weight kernel (ur_conv1x1_pw_wgrad_bn: it multiplies the gradient with the ReLU mask and with mask * xhat, from
+    which both the weight gradient and the sums follow) and one apply pass (mask rebuilt from y) produces dy.  Saves one pass
+    over the tensor in forward (read y, write a), the reduction pass in backward, and the tensor itself."""
 
     @staticmethod
     def forward(ctx, y, gamma, beta, stats, running_mean, running_var, nbt, training, momentum, eps, weight, bias, out):
@@ -1100,23 +1102,33 @@ class _BNReluConv1x1(Function):
         da = empty_nhwc(n, c, h, w, y.dtype, dev)
         with _Timed("pw_dgrad", _conv_flops(d), d):
             call("ur_conv1x1_pw_dgrad", dz.data_ptr(), weight.data_ptr(), cout, c, da.data_ptr(), C.byref(d), _stream())
-        if ctx.needs_input_grad[10]:
-            dw = grad_buffer(weight, (d.cout, c, 1, 1))
-            ws = _workspace(query("ur_conv1x1_pw_wgrad_workspace", C.byref(d)), dev)
-            with _Timed("pw_wgrad", _conv_flops(d), d):
-                call("ur_conv1x1_pw_wgrad_affine", y.data_ptr(), aff.data_ptr(), 1, dz.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-                     ws.numel(), C.byref(d), _stream())
-            if d.cout != cout:
-                dw = dw[:cout].contiguous()
         tb = y.numel() * y.element_size()
-        partial = torch.empty((query("ur_bn_stats_rows", rows, c), c, 2), dtype=torch.float32, device=dev)
-        with _Timed("hbm:bn_bwd_reduce", tb * 2):
-            call("ur_bn_act_bwd_reduce", da.data_ptr(), y.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                 beta.data_ptr(), _lib.ACT_RELU, _dt(y), rows, c, c, partial.data_ptr(), _stream())
         sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
         dgamma, dbeta = grad_buffer(gamma), grad_buffer(beta)
-        call("ur_bn_bwd_finalize", partial.data_ptr(), partial.shape[0], c, sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-             _stream())
+        if fuse_head_bn_sums and not ctx.eval:
+            # weight gradient and the BatchNorm's backward sums from one kernel (see _BNReluConv1x1Pair.backward)
+            if ctx.needs_input_grad[10]:
+                dw = grad_buffer(weight)
+            ws = _workspace(query("ur_conv1x1_pw_wgrad_bn_workspace", C.byref(d)), dev)
+            with _Timed("pw_wgrad", 2 * _conv_flops(d), d):
+                call("ur_conv1x1_pw_wgrad_bn", y.data_ptr(), aff.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                     beta.data_ptr(), dz.data_ptr(), weight.data_ptr(), cout, _p(dw), sums.data_ptr(), dgamma.data_ptr(),
+                     dbeta.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(d), _stream())
+        else:
+            if ctx.needs_input_grad[10]:
+                dw = grad_buffer(weight, (d.cout, c, 1, 1))
+                ws = _workspace(query("ur_conv1x1_pw_wgrad_workspace", C.byref(d)), dev)
+                with _Timed("pw_wgrad", _conv_flops(d), d):
+                    call("ur_conv1x1_pw_wgrad_affine", y.data_ptr(), aff.data_ptr(), 1, dz.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                         ws.numel(), C.byref(d), _stream())
+                if d.cout != cout:
+                    dw = dw[:cout].contiguous()
+            partial = torch.empty((query("ur_bn_stats_rows", rows, c), c, 2), dtype=torch.float32, device=dev)
+            with _Timed("hbm:bn_bwd_reduce", tb * 2):
+                call("ur_bn_act_bwd_reduce", da.data_ptr(), y.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                     beta.data_ptr(), _lib.ACT_RELU, _dt(y), rows, c, c, partial.data_ptr(), _stream())
+            call("ur_bn_bwd_finalize", partial.data_ptr(), partial.shape[0], c, sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                 _stream())
         dy = torch.empty_like(y, memory_format=CL)
         with _Timed("hbm:bn_bwd_apply", tb * 3):
             call("ur_bn_act_bwd_apply", da.data_ptr(), y.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
