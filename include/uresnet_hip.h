@@ -125,6 +125,15 @@ int ur_conv1x1_pw_wgrad_affine_pair(const void* xa, int ca, int ld_a, const void
  *   sums[c] = (sum_co W[co][c] S1, sum_co W[co][c] S2) = (sum g, sum g xhat), also written to dbeta / dgamma (may be NULL),
  * with W rounded to bf16 as ur_conv1x1_pw_dgrad_pair used it.  mean, invstd, gamma, beta: [ca + cb] fp32; aff_a / aff_b: the
  * folded constants of the forward call (the mask is the forward's); w: [w_cout][ca + cb] fp32. */
+/* Backward-data of such a head with the BatchNorm's second backward pass in its epilogue: the product (the gradient of the
+ * activated tensor) is never stored; what is stored is the gradient of the BatchNorm's INPUT v,
+ *   dv = gamma invstd (g' - s0 - xhat s1),  g' = the product where the activation passed, (s0, s1) = sums[c] / (n h w)
+ * (ur_bn_act_bwd_apply's value on the bf16-rounded product, to fp32 rounding), read from va / vb and written to dva / dvb
+ * (two dense tensors of ca and cb channels, pitches ld_a / ld_b, 0 = dense; vb = dvb = NULL: one tensor).  sums = what
+ * ur_conv1x1_pw_wgrad_bn[_pair] returned: call that first.  Saves writing and re-reading the activated tensor's gradient. */
+int ur_conv1x1_pw_dgrad_bn_pair(const void* dy, const float* w, int w_cout, int w_cin, const void* va, void* dva, int ca, int ld_a,
+                                const void* vb, void* dvb, int cb, int ld_b, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, const float* sums, const ur_conv_desc* d, ur_stream_t s);
 size_t ur_conv1x1_pw_wgrad_bn_workspace(const ur_conv_desc* d);
 /* the same over one input tensor (x, pitch d->in_ld): the backward of ur_conv1x1_pw_fwd_affine in training mode (the EUCB*
  * projection behind its last BatchNorm+ReLU, S/C:84-86) */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ur_conv1x1_pw_fwd_affine": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _dp, _vp]),
     "ur_conv1x1_pw_wgrad_bn_workspace": (_sz, [_dp]),
     "ur_conv1x1_pw_wgrad_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _dp, _vp]),
+    "ur_conv1x1_pw_dgrad_bn_pair": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _dp, _vp]),
     "ur_conv1x1_pw_wgrad_bn_pair": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
                                          _vp, _sz, _dp, _vp]),
     "ur_conv1x1_pw_wgrad_affine": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _dp, _vp]),

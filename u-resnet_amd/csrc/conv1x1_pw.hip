@@ -40,6 +40,15 @@ struct PwParams {
     // y2 (pitch out_ld2) when y2 is set.  All boundaries are multiples of 8 channels (whole 16-byte pieces).
     const bf16_t* x2; int K1, in_ld2; const float* in_aff2;
     bf16_t* y2; int M1, out_ld2;
+    // BNA (backward-data of a convolution whose input is relu(BatchNorm(v)) in training mode): the product g is the gradient of
+    // the activated tensor, which is not stored; stored is the BatchNorm's input gradient
+    //   gamma * invstd * (g' - s0 - xhat * s1),  g' = g where the activation passed (xhat * gamma + beta > 0), else 0,
+    //   xhat = (v - mean) * invstd,  (s0, s1) = bn_sums[c] * bn_inv_count
+    // -- ur_bn_act_bwd_apply's value on the bf16-rounded g, to fp32 rounding.  v lies in bn_v (and bn_v2 for the channels that go to y2),
+    // with the pitches of y / y2; the per-channel vectors cover all M channels in order.
+    const bf16_t* bn_v; const bf16_t* bn_v2;
+    const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; const float* bn_sums;
+    float bn_inv_count;
 };
 
 // x -> bf16(max(x * scale + shift, 0)) on 8 consecutive channels; cs = the channels' scales in LDS, their shifts K floats on
@@ -64,7 +73,7 @@ int odd_pitch(int bytes) {
     return q * 16;
 }
 
-template <int MT, int KS, bool BIAS, bool AFF>
+template <int MT, int KS, bool BIAS, bool AFF, bool BNA = false>
 __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -124,12 +133,34 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
         if constexpr (AFF) ich[i] = grp * 8;
     }
     // output pieces: (pixel, group) of M/8 groups per pixel, or plain 16-byte pieces of the contiguous chunk
-    constexpr int NO = 2 * MT;
+    // BNA: a lane keeps ONE channel group (lane % groups) for all its pieces, so that the group's BatchNorm constants fit in
+    // registers: pass i covers pixels (lane / groups) + (64 / groups) i; the lanes beyond groups * (64 / groups) idle
+    constexpr int NO = BNA ? (MT == 1 ? 2 : MT == 2 ? 4 : 7) : 2 * MT;
     const int go = p.M >> 3, pieces_out = p.flat ? (32 * p.M * 2) / 16 : 32 * go;
     int opix[NO], odst[NO], olds[NO];
     bool osecond[NO];                                          // the piece goes to the second tensor
+    // (BNA: piece i of a lane is pixel b_p0 + b_ppp * i of its group: offsets are base + i * stride, nothing is tabulated)
+    const int b_ppp = BNA ? 64 / go : 1, b_grp = BNA ? lane % go : 0, b_p0 = BNA ? lane / go : 0;
+    const bool b_second = BNA && p.y2 != nullptr && b_grp * 8 >= p.M1;
+    const int b_ld = b_second ? p.out_ld2 : p.out_ld;
+    const int b_dst0 = b_second ? b_p0 * p.out_ld2 + b_grp * 8 - p.M1 : b_p0 * p.out_ld + b_grp * 8;
+    const int b_lds0 = b_p0 * p.pitch_out + b_grp * 16;
+    // The BatchNorm's per-channel constants sit behind the four waves' rows, folded to four per channel ([4][M]):
+    //   k = gamma * invstd, sh = beta - mean * k:  the activation passed where v * k + sh > 0 (the forward's own test);
+    //   gamma * invstd * (g' - s0 - xhat * s1) = k * g' + (q * v + r),  q = -k * s1 * invstd,  r = -k * s0 - q * mean
+    const float* bnc = reinterpret_cast<const float*>(lds + (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out));
+    if constexpr (BNA) {
+        float* a = const_cast<float*>(bnc);
+        for (int c = threadIdx.x; c < p.M; c += NT) {
+            const float m = p.bn_mean[c], is = p.bn_invstd[c], k = p.bn_gamma[c] * is;
+            const float s0 = p.bn_sums[2 * c] * p.bn_inv_count, s1 = p.bn_sums[2 * c + 1] * p.bn_inv_count;
+            const float q = -k * s1 * is;
+            a[c] = k; a[p.M + c] = p.bn_beta[c] - m * k; a[2 * p.M + c] = q; a[3 * p.M + c] = -k * s0 - q * m;
+        }
+        __syncthreads();
+    }
 #pragma unroll
-    for (int i = 0; i < NO; ++i) {
+    for (int i = 0; i < (BNA ? 0 : NO); ++i) {
         const int id = i * 64 + lane;
         osecond[i] = false;
         if (p.flat) {
@@ -162,6 +193,17 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     bf16x8_t nxt[KS];
     if (ch < chunks) fetch(ch, nxt);
     for (; ch < chunks; ch += wstep) {
+        bf16x8_t vv[BNA ? NO : 1];
+        if constexpr (BNA) {                                   // the BatchNorm's input at this chunk's output positions
+            const long long first = ch * 32;
+            const int live = (int)(p.P - first < 32 ? p.P - first : 32);
+            const bf16_t* v = (b_second ? p.bn_v2 + first * p.out_ld2 : p.bn_v + first * p.out_ld) + b_dst0;
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const bf16x8_t* q = reinterpret_cast<const bf16x8_t*>(v + i * b_ppp * b_ld);
+                vv[i] = (b_p0 < b_ppp && b_p0 + b_ppp * i < live) ? (UR_PW_NT ? __builtin_nontemporal_load(q) : *q) : zero;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < KS; ++i)
             if (ipix[i] < 32) {
@@ -223,14 +265,43 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
             __builtin_amdgcn_wave_barrier();
             bf16_t* out = p.y + first * p.out_ld;
             bf16_t* out2 = p.y2 ? p.y2 + first * p.out_ld2 : out;
+            if constexpr (BNA) {
+                // the lane's eight channels' constants, fetched here where the accumulators' registers are free again
+                float ck[8], csh[8], cq[8], cr[8];
 #pragma unroll
-            for (int i = 0; i < NO; ++i)
-                if (opix[i] < live) {
-                    const bf16x8_t o8 = *reinterpret_cast<const bf16x8_t*>(lout + olds[i]);
-                    bf16x8_t* q = reinterpret_cast<bf16x8_t*>((osecond[i] ? out2 : out) + odst[i]);
-                    if (UR_PW_NT) __builtin_nontemporal_store(o8, q);
-                    else *q = o8;
+                for (int h = 0; h < 2; ++h) {
+                    const float* c0 = bnc + b_grp * 8 + 4 * h;
+                    const float4 a = *reinterpret_cast<const float4*>(c0), b = *reinterpret_cast<const float4*>(c0 + p.M);
+                    const float4 c = *reinterpret_cast<const float4*>(c0 + 2 * p.M), d = *reinterpret_cast<const float4*>(c0 + 3 * p.M);
+                    const float ak[4] = {a.x, a.y, a.z, a.w}, bs[4] = {b.x, b.y, b.z, b.w}, cc[4] = {c.x, c.y, c.z, c.w}, dr[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ck[4 * h + j] = ak[j]; csh[4 * h + j] = bs[j]; cq[4 * h + j] = cc[j]; cr[4 * h + j] = dr[j]; }
                 }
+                bf16_t* o = (b_second ? out2 : out) + b_dst0;
+#pragma unroll
+                for (int i = 0; i < NO; ++i)
+                    if (b_p0 < b_ppp && b_p0 + b_ppp * i < live) {
+                        bf16x8_t o8 = *reinterpret_cast<const bf16x8_t*>(lout + b_lds0 + i * b_ppp * p.pitch_out);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = (float)vv[i][e];
+                            const float gv = fmaf(v, ck[e], csh[e]) > 0.f ? (float)o8[e] : 0.f;
+                            o8[e] = (bf16_t)fmaf(ck[e], gv, fmaf(cq[e], v, cr[e]));
+                        }
+                        bf16x8_t* q = reinterpret_cast<bf16x8_t*>(o + i * b_ppp * b_ld);
+                        if (UR_PW_NT) __builtin_nontemporal_store(o8, q);
+                        else *q = o8;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NO; ++i)
+                    if (opix[i] < live) {
+                        const bf16x8_t o8 = *reinterpret_cast<const bf16x8_t*>(lout + olds[i]);
+                        bf16x8_t* q = reinterpret_cast<bf16x8_t*>((osecond[i] ? out2 : out) + odst[i]);
+                        if (UR_PW_NT) __builtin_nontemporal_store(o8, q);
+                        else *q = o8;
+                    }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -255,17 +326,18 @@ size_t lds_bytes(int K, int M, int out_ld) {
 
 // One resident round: as many workgroups as the device holds at this instantiation's register count, so that every
 // wave walks the same number of chunks and all finish together (no partially filled last round).
-template <int MT, int KS, bool BIAS, bool AFF>
+template <int MT, int KS, bool BIAS, bool AFF, bool BNA = false>
 void launch_one(long long chunks, hipStream_t st, const PwParams& p) {
-    const size_t lds = (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out) + (AFF ? (size_t)2 * p.K * sizeof(float) : 0);
+    const size_t lds = (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out) + (AFF ? (size_t)2 * p.K * sizeof(float) : 0) +
+                       (BNA ? (size_t)4 * p.M * sizeof(float) : 0);
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1x1_pw_kernel<MT, KS, BIAS, AFF>, NT, lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1x1_pw_kernel<MT, KS, BIAS, AFF, BNA>, NT, lds) != hipSuccess || per_cu < 1)
         per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
         cus = 256;
     const unsigned grid = (unsigned)ur_grid_1d(chunks, NT / 64, per_cu * cus);
-    hipLaunchKernelGGL((conv1x1_pw_kernel<MT, KS, BIAS, AFF>), dim3(grid), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((conv1x1_pw_kernel<MT, KS, BIAS, AFF, BNA>), dim3(grid), dim3(NT), lds, st, p);
 }
 
 template <int MT>
@@ -283,6 +355,17 @@ int launch_ks(int ks, long long chunks, hipStream_t st, const PwParams& p) {
         UR_PW_CASE(1) UR_PW_CASE(2) UR_PW_CASE(3) UR_PW_CASE(4) UR_PW_CASE(5)
 #undef UR_PW_CASE
         default: ur_set_error("conv1x1_pw: %d reduction steps", ks); return UR_ERR_INVALID;
+    }
+    return ur_check_launch("conv1x1_pw");
+}
+
+// the BNA instantiations: backward-data shapes of the heads (24 -> 80: MT 3, KS 2; 16 -> 32: MT 1, KS 1) and their neighbours
+template <int MT>
+int launch_bna(int ks, long long chunks, hipStream_t st, const PwParams& p) {
+    switch (ks) {
+        case 1: launch_one<MT, 1, false, false, true>(chunks, st, p); break;
+        case 2: launch_one<MT, 2, false, false, true>(chunks, st, p); break;
+        default: ur_set_error("conv1x1_pw (BatchNorm backward in the epilogue): %d reduction steps", ks); return UR_ERR_INVALID;
     }
     return ur_check_launch("conv1x1_pw");
 }
@@ -309,6 +392,16 @@ int launch(PwParams p, hipStream_t st) {
                    "conv1x1_pw: the two-tensor output needs 8 | channel split and pitches and 16-byte alignment");
     if (p.P <= 0) return UR_OK;
     const long long chunks = (p.P + 31) / 32;
+    if (p.bn_v) {
+        UR_REQUIRE(!p.flat && !p.bias && !p.in_aff && ks <= 2 && p.M >= 8, "conv1x1_pw: BatchNorm backward in the epilogue needs 8 | channels and <= 32 reduced channels");
+        UR_REQUIRE(((uintptr_t)p.bn_v & 15) == 0 && ((uintptr_t)p.bn_v2 & 15) == 0 && (!p.y2) == (!p.bn_v2),
+                   "conv1x1_pw: the BatchNorm input must be 16-byte aligned and split as the output is");
+        switch (mt) {
+            case 1: return launch_bna<1>(ks, chunks, st, p);
+            case 2: return launch_bna<2>(ks, chunks, st, p);
+            default: return launch_bna<3>(ks, chunks, st, p);
+        }
+    }
     switch (mt) {
         case 1: return launch_ks<1>(ks, chunks, st, p);
         case 2: return launch_ks<2>(ks, chunks, st, p);
@@ -387,6 +480,26 @@ int ur_conv1x1_pw_dgrad_pair(const void* dy, const float* w, int w_cout, int w_c
     p.K = d->cout; p.M = d->cin; p.in_ld = d->out_ld ? d->out_ld : d->cout; p.out_ld = ld_a ? ld_a : ca;
     p.wM = w_cin; p.wK = w_cout; p.sm = 1; p.sk = w_cin;
     p.y2 = (bf16_t*)dxb; p.M1 = ca; p.out_ld2 = ld_b ? ld_b : cb;
+    return launch(p, (hipStream_t)s);
+}
+
+int ur_conv1x1_pw_dgrad_bn_pair(const void* dy, const float* w, int w_cout, int w_cin, const void* va, void* dva, int ca, int ld_a,
+                                const void* vb, void* dvb, int cb, int ld_b, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, const float* sums, const ur_conv_desc* d, ur_stream_t s) {
+    UR_REQUIRE(dy && w && va && dva && mean && invstd && gamma && beta && sums && d, "conv1x1_pw_dgrad_bn_pair: null argument");
+    UR_REQUIRE((vb == nullptr) == (dvb == nullptr), "conv1x1_pw_dgrad_bn_pair: the second tensor needs both its input and its gradient");
+    UR_REQUIRE(shape_ok(d), "conv1x1_pw_dgrad_bn_pair: not a bf16 1x1 stride-1 convolution");
+    UR_REQUIRE(ca + (vb ? cb : 0) == d->cin && w_cout <= d->cout && w_cin <= d->cin,
+               "conv1x1_pw_dgrad_bn_pair: %d + %d channels against a descriptor of %d, weight %dx%d", ca, vb ? cb : 0, d->cin, w_cout, w_cin);
+    PwParams p{};
+    p.x = (const bf16_t*)dy; p.w = w; p.bias = nullptr; p.y = (bf16_t*)dva;
+    p.P = (long long)d->n * d->h * d->w;
+    p.K = d->cout; p.M = d->cin; p.in_ld = d->out_ld ? d->out_ld : d->cout; p.out_ld = ld_a ? ld_a : ca;
+    p.wM = w_cin; p.wK = w_cout; p.sm = 1; p.sk = w_cin;
+    if (vb) { p.y2 = (bf16_t*)dvb; p.M1 = ca; p.out_ld2 = ld_b ? ld_b : cb; }
+    p.bn_v = (const bf16_t*)va; p.bn_v2 = (const bf16_t*)vb;
+    p.bn_mean = mean; p.bn_invstd = invstd; p.bn_gamma = gamma; p.bn_beta = beta; p.bn_sums = sums;
+    p.bn_inv_count = 1.f / (float)p.P;
     return launch(p, (hipStream_t)s);
 }
 

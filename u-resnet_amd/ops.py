@@ -1098,10 +1098,12 @@ class _BNReluConv1x1(Function):
             if d.cout != cout:
                 dz, dz_ld = _pad_channels(dz, d.cout), d.cout
         d.out_ld = dz_ld
-        # gradient of the activated tensor a = relu(BatchNorm(y)), which exists in no buffer
-        da = empty_nhwc(n, c, h, w, y.dtype, dev)
-        with _Timed("pw_dgrad", _conv_flops(d), d):
-            call("ur_conv1x1_pw_dgrad", dz.data_ptr(), weight.data_ptr(), cout, c, da.data_ptr(), C.byref(d), _stream())
+        fused_apply = fuse_head_bn_sums and fuse_head_bn_apply and not ctx.eval
+        if not fused_apply:
+            # gradient of the activated tensor a = relu(BatchNorm(y)), which exists in no buffer
+            da = empty_nhwc(n, c, h, w, y.dtype, dev)
+            with _Timed("pw_dgrad", _conv_flops(d), d):
+                call("ur_conv1x1_pw_dgrad", dz.data_ptr(), weight.data_ptr(), cout, c, da.data_ptr(), C.byref(d), _stream())
         tb = y.numel() * y.element_size()
         sums = torch.empty((c, 2), dtype=torch.float32, device=dev)
         dgamma, dbeta = grad_buffer(gamma), grad_buffer(beta)
@@ -1130,6 +1132,12 @@ class _BNReluConv1x1(Function):
             call("ur_bn_bwd_finalize", partial.data_ptr(), partial.shape[0], c, sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                  _stream())
         dy = torch.empty_like(y, memory_format=CL)
+        if fused_apply:                      # the BatchNorm's second pass in the backward-data kernel's epilogue (see the pair)
+            with _Timed("pw_dgrad", _conv_flops(d), d):
+                call("ur_conv1x1_pw_dgrad_bn_pair", dz.data_ptr(), weight.data_ptr(), cout, c, y.data_ptr(), dy.data_ptr(), c, c,
+                     None, None, 0, 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
+                     C.byref(d), _stream())
+            return dy, dgamma, dbeta, None, None, None, None, None, None, None, dw, db, None
         with _Timed("hbm:bn_bwd_apply", tb * 3):
             call("ur_bn_act_bwd_apply", da.data_ptr(), y.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                  beta.data_ptr(), sums.data_ptr(), _lib.ACT_RELU, int(ctx.eval), dy.data_ptr(), None, _dt(y), rows, c, c,
@@ -1233,14 +1241,16 @@ class _BNReluConv1x1Pair(Function):
             if d.cout != cout:
                 dz, dz_ld = _pad_channels(dz, d.cout), d.cout
         d.out_ld = dz_ld
-        # gradients of the two halves of the activated tensor a = relu(BatchNorm(cat)), which exists in no buffer
-        da = (empty_nhwc(n, ca, h, w, ya.dtype, dev), empty_nhwc(n, cb, h, w, ya.dtype, dev))
-        with _Timed("pw_dgrad", _conv_flops(d), d):
-            call("ur_conv1x1_pw_dgrad_pair", dz.data_ptr(), weight.data_ptr(), cout, c, da[0].data_ptr(), ca, ca, da[1].data_ptr(),
-                 cb, cb, C.byref(d), _stream())
         dgamma, dbeta = grad_buffer(gamma), grad_buffer(beta)
         off = lambda t, o: t.data_ptr() + 4 * o      # noqa: E731
         all_sums = None
+        fused_apply = fuse_head_bn_sums and fuse_head_bn_apply and not ctx.eval
+        if not fused_apply:
+            # gradients of the two halves of the activated tensor a = relu(BatchNorm(cat)), which exists in no buffer
+            da = (empty_nhwc(n, ca, h, w, ya.dtype, dev), empty_nhwc(n, cb, h, w, ya.dtype, dev))
+            with _Timed("pw_dgrad", _conv_flops(d), d):
+                call("ur_conv1x1_pw_dgrad_pair", dz.data_ptr(), weight.data_ptr(), cout, c, da[0].data_ptr(), ca, ca, da[1].data_ptr(),
+                     cb, cb, C.byref(d), _stream())
         if fuse_head_bn_sums and not ctx.eval:
             # the backward-weight kernel multiplies the gradient with the ReLU mask and with mask * xhat: the weight gradient
             # and the BatchNorm's backward sums both follow from those two products (ur_conv1x1_pw_wgrad_bn_pair), and the
@@ -1262,6 +1272,15 @@ class _BNReluConv1x1Pair(Function):
                      aff_b.data_ptr(), 1, dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(d), _stream())
             if d.cout != cout:
                 dw = dw[:cout].contiguous()
+        if fused_apply:
+            # the sums are known before the backward-data kernel runs, so the BatchNorm's second pass moves into its epilogue:
+            # the gradient of the activated tensor is neither written nor read back
+            dys = [torch.empty_like(ya, memory_format=CL), torch.empty_like(yb, memory_format=CL)]
+            with _Timed("pw_dgrad", _conv_flops(d), d):
+                call("ur_conv1x1_pw_dgrad_bn_pair", dz.data_ptr(), weight.data_ptr(), cout, c, ya.data_ptr(), dys[0].data_ptr(), ca, ca,
+                     yb.data_ptr(), dys[1].data_ptr(), cb, cb, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                     all_sums.data_ptr(), C.byref(d), _stream())
+            return dys[0], dys[1], dgamma, dbeta, None, None, None, None, None, None, dw, db, None
         dys = []
         for y, g, o, ci in ((ya, da[0], 0, ca), (yb, da[1], ca, cb)):
             tb = y.numel() * y.element_size()
@@ -1286,6 +1305,7 @@ class _BNReluConv1x1Pair(Function):
 
 fuse_merge_into_head = os.environ.get("URESNET_MERGE_PAIR", "1") != "0"    # False: the Feature Merge builds the merged tensor
 fuse_head_bn_sums = os.environ.get("URESNET_HEAD_BN_SUMS", "1") != "0"    # False: the head's BatchNorm backward reduces over its input gradient
+fuse_head_bn_apply = os.environ.get("URESNET_HEAD_BN_APPLY", "1") != "0"   # False: ... and applies in a pass of its own (needs the sums fused)
 
 
 def bn_relu_conv1x1_pair_supported(n, ca, cb, h, w, dtype, bn, conv):
