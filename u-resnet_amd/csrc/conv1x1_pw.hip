@@ -66,6 +66,16 @@ __device__ __forceinline__ bf16x8_t pw_affine8(const bf16x8_t& v, const float* c
     return o;
 }
 
+// Asynchronous global -> LDS copy (LDS-DMA): every lane supplies its own 16-byte source, the data land at (wave-uniform) LDS
+// byte address dst + lane * 16; inactive lanes copy nothing.  Counted in vmcnt.
+__device__ __forceinline__ void pw_lds_dma16(const void* src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
 // LDS row pitch for rows of `bytes`: the next odd multiple of 16 bytes above it
 int odd_pitch(int bytes) {
     int q = bytes / 16 + 1;
@@ -74,14 +84,18 @@ int odd_pitch(int bytes) {
 }
 
 template <int MT, int KS, bool BIAS, bool AFF, bool BNA = false>
-__global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void conv1x1_pw_kernel(PwParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 31, half = lane >> 5;
-    unsigned char* lin = lds + (size_t)wave * 32 * (p.pitch_in + p.pitch_out);
+    // per wave: input rows, output rows and (BNA) two buffers of 2 MT KiB for the BatchNorm input of this and the next chunk
+    constexpr int VBUF = BNA ? 2 * MT * 1024 : 0;
+    const size_t wave_bytes = (size_t)32 * (p.pitch_in + p.pitch_out) + 2 * VBUF;
+    unsigned char* lin = lds + (size_t)wave * wave_bytes;
     unsigned char* lout = lin + 32 * p.pitch_in;
+    unsigned char* vbuf = lout + 32 * p.pitch_out;
     // AFF: the input's per-channel constants sit behind the four waves' rows (the only workgroup barrier of the kernel)
-    const float* aff = reinterpret_cast<const float*>(lds + (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out));
+    const float* aff = reinterpret_cast<const float*>(lds + (size_t)(NT / 64) * wave_bytes);
     if constexpr (AFF) {
         float* a = const_cast<float*>(aff);
         const int ka = p.in_aff2 ? p.K1 : p.K;                 // channels whose constants are in in_aff
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     // output pieces: (pixel, group) of M/8 groups per pixel, or plain 16-byte pieces of the contiguous chunk
     // BNA: a lane keeps ONE channel group (lane % groups) for all its pieces, so that the group's BatchNorm constants fit in
     // registers: pass i covers pixels (lane / groups) + (64 / groups) i; the lanes beyond groups * (64 / groups) idle
-    constexpr int NO = BNA ? (MT == 1 ? 2 : MT == 2 ? 4 : 7) : 2 * MT;
+    constexpr int NO = 2 * MT, NB = MT == 1 ? 2 : MT == 2 ? 4 : 7;      // pieces per lane: dense order / BNA passes
     const int go = p.M >> 3, pieces_out = p.flat ? (32 * p.M * 2) / 16 : 32 * go;
     int opix[NO], odst[NO], olds[NO];
     bool osecond[NO];                                          // the piece goes to the second tensor
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
     // The BatchNorm's per-channel constants sit behind the four waves' rows, folded to four per channel ([4][M]):
     //   k = gamma * invstd, sh = beta - mean * k:  the activation passed where v * k + sh > 0 (the forward's own test);
     //   gamma * invstd * (g' - s0 - xhat * s1) = k * g' + (q * v + r),  q = -k * s1 * invstd,  r = -k * s0 - q * mean
-    const float* bnc = reinterpret_cast<const float*>(lds + (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out));
+    const float* bnc = reinterpret_cast<const float*>(lds + (size_t)(NT / 64) * wave_bytes);
     if constexpr (BNA) {
         float* a = const_cast<float*>(bnc);
         for (int c = threadIdx.x; c < p.M; c += NT) {
@@ -190,20 +204,37 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
         }
     };
 
-    bf16x8_t nxt[KS];
-    if (ch < chunks) fetch(ch, nxt);
-    for (; ch < chunks; ch += wstep) {
-        bf16x8_t vv[BNA ? NO : 1];
-        if constexpr (BNA) {                                   // the BatchNorm's input at this chunk's output positions
-            const long long first = ch * 32;
-            const int live = (int)(p.P - first < 32 ? p.P - first : 32);
-            const bf16_t* v = (b_second ? p.bn_v2 + first * p.out_ld2 : p.bn_v + first * p.out_ld) + b_dst0;
+    // BNA: the BatchNorm's input at a chunk's output positions goes straight to LDS (LDS-DMA, no registers), in the dense
+    // piece order (pixel, group) -- which is where a lane of the output stage finds its pieces: lane + pass * (64 / go) * go.
+    // The copy for chunk c + 1 is issued before chunk c is worked on, so it has a whole iteration to land.
+    auto fetch_v = [&](long long chunk, int buf) {
+        const long long first = chunk * 32;
+        const int live = (int)(p.P - first < 32 ? p.P - first : 32);
+        const bf16_t* v1 = p.bn_v + first * p.out_ld;
+        const bf16_t* v2 = p.bn_v2 ? p.bn_v2 + first * p.out_ld2 : v1;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)vbuf + buf * VBUF);
+        // piece i * 64 + lane = (pixel, group), stepped from piece `lane` without a division (and without a table: registers)
+        int pix = b_p0, grp = b_grp;
+        asm volatile("" : "+v"(pix), "+v"(grp));               // (or the compiler keeps all the addresses in registers across the loop)
+        const int dg = 64 - b_ppp * go;
 #pragma unroll
-            for (int i = 0; i < NO; ++i) {
-                const bf16x8_t* q = reinterpret_cast<const bf16x8_t*>(v + i * b_ppp * b_ld);
-                vv[i] = (b_p0 < b_ppp && b_p0 + b_ppp * i < live) ? (UR_PW_NT ? __builtin_nontemporal_load(q) : *q) : zero;
+        for (int i = 0; i < NO; ++i) {
+            if (pix < live) {
+                const bool second = p.bn_v2 != nullptr && grp * 8 >= p.M1;
+                pw_lds_dma16(second ? v2 + pix * p.out_ld2 + grp * 8 - p.M1 : v1 + pix * p.out_ld + grp * 8, dst + i * 1024);
             }
+            pix += b_ppp; grp += dg;
+            if (grp >= go) { grp -= go; pix += 1; }
         }
+    };
+    bf16x8_t nxt[KS];
+    int vb = 0;
+    if (ch < chunks) {
+        fetch(ch, nxt);
+        if constexpr (BNA) fetch_v(ch, 0);
+    }
+    for (; ch < chunks; ch += wstep) {
+        if constexpr (BNA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk's copy has landed
 #pragma unroll
         for (int i = 0; i < KS; ++i)
             if (ipix[i] < 32) {
@@ -212,7 +243,10 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (ch + wstep < chunks) fetch(ch + wstep, nxt);
+        if (ch + wstep < chunks) {
+            fetch(ch + wstep, nxt);
+            if constexpr (BNA) fetch_v(ch + wstep, vb ^ 1);
+        }
         bf16x8_t cur[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -277,14 +311,19 @@ __global__ __launch_bounds__(NT) void conv1x1_pw_kernel(PwParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { ck[4 * h + j] = ak[j]; csh[4 * h + j] = bs[j]; cq[4 * h + j] = cc[j]; cr[4 * h + j] = dr[j]; }
                 }
-                bf16_t* o = (b_second ? out2 : out) + b_dst0;
+                int dst0 = b_dst0, lds0 = b_lds0, l16 = lane * 16;
+                asm volatile("" : "+v"(dst0), "+v"(lds0), "+v"(l16));     // (as above)
+                bf16_t* o = (b_second ? out2 : out) + dst0;
+                const unsigned char* vsrc = vbuf + vb * VBUF + l16;
+                vb ^= 1;
 #pragma unroll
-                for (int i = 0; i < NO; ++i)
+                for (int i = 0; i < NB; ++i)
                     if (b_p0 < b_ppp && b_p0 + b_ppp * i < live) {
-                        bf16x8_t o8 = *reinterpret_cast<const bf16x8_t*>(lout + b_lds0 + i * b_ppp * p.pitch_out);
+                        bf16x8_t o8 = *reinterpret_cast<const bf16x8_t*>(lout + lds0 + i * b_ppp * p.pitch_out);
+                        const bf16x8_t v8 = *reinterpret_cast<const bf16x8_t*>(vsrc + i * b_ppp * go * 16);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float v = (float)vv[i][e];
+                            const float v = (float)v8[e];
                             const float gv = fmaf(v, ck[e], csh[e]) > 0.f ? (float)o8[e] : 0.f;
                             o8[e] = (bf16_t)fmaf(ck[e], gv, fmaf(cq[e], v, cr[e]));
                         }
@@ -328,9 +367,12 @@ size_t lds_bytes(int K, int M, int out_ld) {
 // wave walks the same number of chunks and all finish together (no partially filled last round).
 template <int MT, int KS, bool BIAS, bool AFF, bool BNA = false>
 void launch_one(long long chunks, hipStream_t st, const PwParams& p) {
-    const size_t lds = (size_t)(NT / 64) * 32 * (p.pitch_in + p.pitch_out) + (AFF ? (size_t)2 * p.K * sizeof(float) : 0) +
-                       (BNA ? (size_t)4 * p.M * sizeof(float) : 0);
+    const size_t lds = (size_t)(NT / 64) * (32 * (p.pitch_in + p.pitch_out) + (BNA ? 4 * MT * 1024 : 0)) +
+                       (AFF ? (size_t)2 * p.K * sizeof(float) : 0) + (BNA ? (size_t)4 * p.M * sizeof(float) : 0);
     int per_cu = 0, dev = 0, cus = 0;
+    if (BNA && lds > 64 * 1024)              // (more than the default limit of dynamic LDS per workgroup; a CU has 160 KiB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_pw_kernel<MT, KS, BIAS, AFF, BNA>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1x1_pw_kernel<MT, KS, BIAS, AFF, BNA>, NT, lds) != hipSuccess || per_cu < 1)
         per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess ||
