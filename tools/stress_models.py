@@ -13,7 +13,8 @@ dev = torch.device("cuda:0")
 
 SWITCHES = [(ops, "use_tile_kernel"), (ops, "use_wide_kernel"), (ops, "use_pw_kernel"), (ops, "fuse_bn_bwd_sums"),
             (ops, "fuse_pool_bn_sums"), (ops, "fuse_bn_into_conv1x1"), (ops, "branch_streams"), (_blocks, "fuse_pool_skip"),
-            (_blocks, "fuse_residual_grad")]
+            (_blocks, "fuse_residual_grad"), (ops, "fuse_merge_into_head"), (ops, "fuse_bn_pool"), (ops, "fuse_bn_out_stats"),
+            (ops, "fuse_head_bn_sums"), (ops, "fuse_head_bn_apply"), (ops, "fuse_ce_head_grad")]
 
 
 def rel(a, b):
@@ -93,9 +94,69 @@ def block_cases(n_cases, seed):
     print("block stress OK: %d cases (seed %d), worst gradient difference %.2e" % (n_cases, seed, worst))
 
 
+HEAD_SWITCHES = [(ops, "fuse_head_bn_sums"), (ops, "fuse_head_bn_apply"), (ops, "fuse_ce_head_grad")]
+
+
+def head_cases(n_cases, seed):
+    """BatchNorm -> ReLU -> 1x1 convolution heads over one tensor or a pair of tensors at random channel counts and ragged pixel
+    counts: backward with the BatchNorm sums from the backward-weight kernel and the apply pass in the backward-data kernel
+    against the separate passes (same forward, so the masks are identical)."""
+    B = _blocks
+    rnd = random.Random(seed + 2)
+    worst = 0.0
+    for case in range(n_cases):
+        ca, cb = rnd.choice([8, 16, 32, 64]), rnd.choice([0, 8, 16, 24])
+        if ca + cb > 80:
+            cb = 80 - ca
+        classes = rnd.choice([3, 8, 16, 19, 21])
+        n, h, w = rnd.choice([1, 2]), rnd.randint(190, 330), rnd.randint(181, 350)
+        torch.manual_seed(case)
+        head = B.OutConv(ca + cb, classes).to(dev).train()
+        with torch.no_grad():
+            head[0].weight.uniform_(0.5, 1.5); head[0].bias.uniform_(-0.3, 0.3)
+        a0, b0 = torch.randn(n, ca, h, w, device=dev) + 0.2, torch.randn(n, max(cb, 8), h, w, device=dev)[:, :cb] * 0.7
+        g0 = torch.randn(n, classes, h, w, device=dev)
+        res = {}
+        for fused in (False, True):
+            saved = [(m, k, getattr(m, k)) for m, k in HEAD_SWITCHES]
+            for m, k in HEAD_SWITCHES:
+                setattr(m, k, fused)
+            try:
+                head.zero_grad(set_to_none=True)
+                xa = ops.as_activation(a0, torch.bfloat16).detach().requires_grad_(True)
+                if cb:
+                    xb = ops.as_activation(b0.contiguous(), torch.bfloat16).detach().requires_grad_(True)
+                    out = ops.bn_relu_conv1x1_pair(xa, xb, head[0], head[2])
+                else:
+                    xb = None
+                    out = ops.bn_relu_conv1x1(xa, head[0], head[2])
+                if out is None:
+                    break
+                out.backward(ops.as_activation(g0, torch.bfloat16))
+                torch.cuda.synchronize()
+                res[fused] = ([ops.dense(t.grad).float().cpu() for t in (xa, xb) if t is not None],
+                              {k: p.grad.float().cpu() for k, p in head.named_parameters()})
+            finally:
+                for m, k, v in saved:
+                    setattr(m, k, v)
+        if len(res) < 2:
+            print("head case %2d %2d + %2d -> %2d  %d x %3d x %3d  not covered by the streaming kernels" % (case, ca, cb, classes, n, h, w))
+            continue
+        e_dx = max(rel(a, b) for a, b in zip(res[True][0], res[False][0]))
+        e_p = max(rel(res[True][1][k], res[False][1][k]) for k in res[True][1])
+        worst = max(worst, e_dx, e_p)
+        print("head case %2d %2d + %2d -> %2d  %d x %3d x %3d  input gradients %.2e  parameter gradients max %.2e" % (
+            case, ca, cb, classes, n, h, w, e_dx, e_p), flush=True)
+        if e_dx > 2e-3 or e_p > 6e-3 or not all(torch.isfinite(t).all() for t in res[True][0]):
+            print("MISMATCH in head case %d" % case)
+            sys.exit(1)
+    print("head stress OK: %d cases (seed %d), worst gradient difference %.2e" % (n_cases, seed, worst))
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    head_cases(n_cases, seed)
     block_cases(2 * n_cases, seed)
     rnd = random.Random(seed)
     U = uresnet_amd.modules.U_ResNet
