@@ -1953,6 +1953,61 @@ def test_single_tensor_head_batchnorm_backward_sums_from_the_backward_weight_ker
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,ca,cb,cout", [(2, 200, 170, 64, 16, 19), (1, 263, 251, 32, 0, 16), (1, 301, 219, 8, 24, 5), (3, 150, 150, 48, 16, 24)])
+def test_backward_data_with_the_batchnorm_apply_in_its_epilogue_equals_the_two_kernels(pkg, n, h, w, ca, cb, cout):
+    """ur_conv1x1_pw_dgrad_bn_pair against ur_conv1x1_pw_dgrad[_pair] followed by ur_bn_act_bwd_apply on each tensor, through the
+    C ABI with the same sums: the fused kernel rounds the product to bf16 as the stored gradient would be and evaluates the
+    same expression with folded constants, so the results agree to one bf16 unit on isolated elements (fp32 rounding just
+    before the final cast) -- asserted as at most 1e-3 of the elements differing, at most 1e-5 of them by more than 2 bf16
+    units (ReLU tests within rounding of zero), and rel-L2 < 1e-3.  One and two tensors, ragged pixel counts, 8 to 80 channels."""
+    L = pkg._lib
+    import ctypes as C
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    g = torch.Generator().manual_seed(n * h + ca)
+    c, cpad, rows = ca + cb, (cout + 7) // 8 * 8, n * h * w
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(DEV)  # noqa: E731
+    va, vb = (rnd(n, h, w, ca) * 1.5 + 0.3).to(torch.bfloat16), ((rnd(n, h, w, cb) * 0.7).to(torch.bfloat16) if cb else None)
+    dz = torch.zeros(n, h, w, cpad, dtype=torch.bfloat16, device=DEV)
+    dz[..., :cout] = rnd(n, h, w, cout).to(torch.bfloat16)
+    wt = rnd(cout, c) * 0.2
+    mean, invstd = rnd(c) * 0.2 + 0.3, torch.rand(c, generator=g).to(DEV) + 0.5
+    gamma, beta = torch.rand(c, generator=g).to(DEV) + 0.5, rnd(c) * 0.3
+    gamma[0] = -0.7                                                    # a negative scale flips the mask's sense
+    sums = torch.stack([rnd(c) * rows * 0.05, rnd(c) * rows * 0.05], 1).contiguous()
+    d = L.ConvDesc(L.UR_BF16, n, h, w, c, h, w, cpad, 1, 1, 1, 0, c, cpad)
+    # separate kernels
+    da, db = torch.empty_like(va), (torch.empty_like(vb) if cb else None)
+    if cb:
+        L.call("ur_conv1x1_pw_dgrad_pair", vp(dz), vp(wt), cout, c, vp(da), ca, ca, vp(db), cb, cb, C.byref(d), st)
+    else:
+        L.call("ur_conv1x1_pw_dgrad", vp(dz), vp(wt), cout, c, vp(da), C.byref(d), st)
+    ref = []
+    for gr, v, o, ci in ((da, va, 0, ca), (db, vb, ca, cb)):
+        if not ci:
+            continue
+        out = torch.empty_like(v)
+        off = lambda t: C.c_void_p(t.data_ptr() + 4 * o)  # noqa: E731
+        L.call("ur_bn_act_bwd_apply", vp(gr), vp(v), None, off(mean), off(invstd), off(gamma), off(beta), C.c_void_p(sums.data_ptr() + 8 * o),
+               L.ACT_RELU, 0, vp(out), None, L.UR_BF16, rows, ci, ci, st)
+        ref.append(out)
+    # fused
+    fa, fb = torch.full_like(va, float("nan")), (torch.full_like(vb, float("nan")) if cb else None)
+    L.call("ur_conv1x1_pw_dgrad_bn_pair", vp(dz), vp(wt), cout, c, vp(va), vp(fa), ca, ca, vp(vb), vp(fb), cb, cb, vp(mean), vp(invstd),
+           vp(gamma), vp(beta), vp(sums), C.byref(d), st)
+    torch.cuda.synchronize()
+    for got, want in zip((fa, fb) if cb else (fa,), ref):
+        assert torch.isfinite(got.float()).all()
+        diff = (got.float() - want.float()).abs()
+        ulp = want.float().abs().clamp_min(1e-30) * 2.0 ** -7           # one bf16 unit at the value's magnitude (upper bound)
+        assert (diff > 0).float().mean().item() < 1e-3
+        # beyond two units only where the ReLU test itself sits within fp32 rounding of zero (the fused kernel evaluates the
+        # forward's v * k + shift, the separate pass xhat * gamma + beta): a handful of elements per million
+        assert (diff > 2 * ulp + 1e-30).float().mean().item() < 1e-5
+        assert rel_l2(got.float().cpu(), want.float().cpu()) < 1e-3
+
+
+@pytest.mark.gpu
 def test_two_branch_model_without_the_merged_tensor_matches_the_model_with_it(pkg):
     """UResNetNewEUCB (S/C:214-345) with the Feature Merge read as two tensors by the head against the same model writing
     both branches into one 80-channel tensor: loss and every gradient after one backward pass agree to bf16 rounding."""
